@@ -1,0 +1,111 @@
+/*
+ * srt_raster.h — C ABI of the MI355X (gfx950) rasterizer hot path.
+ *
+ * Drop-in boundary for the DrawSVG software rasterizer of the reference
+ * (paths below are relative to /root/reference/Assignments/DrawSVG/):
+ *
+ *   srt_raster_set_target   <- SoftwareRendererImp::set_render_target  src/software_renderer.cpp:73-92
+ *                              + SoftwareRendererImp::set_sample_rate  src/software_renderer.cpp:55-70
+ *   srt_raster_clear        <- SoftwareRendererImp::clear_target       src/software_renderer.h:93-98
+ *   srt_raster_submit       <- the ordered calls draw_svg/draw_element make into
+ *                              rasterize_triangle  src/software_renderer.cpp:456-516 (+ inside_triangle :519-538,
+ *                                                   fill_sample :634-658)
+ *                              rasterize_point     src/software_renderer.cpp:272-301
+ *   srt_raster_resolve      <- SoftwareRendererImp::resolve            src/software_renderer.cpp:573-622
+ *
+ * The host element walk (draw_svg / draw_element / transform stack / Xiaolin-Wu line
+ * decomposition, src/software_renderer.cpp:17-52,94-265,303-454) stays on the host: it
+ * produces the ORDERED primitive stream that is handed to srt_raster_submit. Painter's
+ * order is part of the contract: primitives are blended in stream order.
+ *
+ * Conventions: every entry point returns 0 on success and a negative srt_status on
+ * failure; srt_last_error() returns a thread-local message. No exceptions cross the ABI.
+ * The caller owns every host buffer. One context may be used by one thread at a time.
+ * There is NO CPU fallback: without a HIP device srt_raster_create fails.
+ */
+#ifndef SRT_RASTER_H
+#define SRT_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum srt_status {
+    SRT_OK = 0,
+    SRT_ERR_INVALID = -1,     /* bad argument */
+    SRT_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    SRT_ERR_HIP = -3,         /* a HIP runtime call failed */
+    SRT_ERR_UNSUPPORTED = -4, /* valid in the reference, not supported by this path */
+    SRT_ERR_STATE = -5        /* call order violated (e.g. submit before set_target) */
+} srt_status;
+
+/* Primitive kinds of the ordered stream. */
+enum {
+    SRT_PRIM_TRIANGLE = 1, /* rasterize_triangle(x0,y0,x1,y1,x2,y2,color) — args already narrowed to float */
+    SRT_PRIM_POINT = 2     /* rasterize_point(x,y,color) — args are double, sr*sr block fill */
+};
+
+/* One 48-byte record of the ordered stream. Screen-space coordinates (pixels). */
+typedef struct srt_prim {
+    uint32_t kind;
+    uint32_t reserved; /* must be 0 */
+    union {
+        float tri[6];     /* x0 y0 x1 y1 x2 y2 — the six float parameters of rasterize_triangle */
+        double point[2];  /* x y — the two double parameters of rasterize_point */
+    } v;
+    float rgba[4]; /* CMU462::Color r g b a, NOT premultiplied (fill_sample semantics) */
+} srt_prim;
+
+typedef struct srt_raster srt_raster; /* opaque */
+
+/* Per-frame work counters (optional, filled by srt_raster_stats). */
+typedef struct srt_raster_stats_t {
+    uint64_t sample_tests;           /* inside_triangle evaluations the reference performs (bbox area, unclipped) */
+    uint64_t sample_tests_in_target; /* the subset that lies inside the sample grid (what the kernel evaluates) */
+    uint64_t fragments;      /* covered, in-bounds fill_sample calls reached from rasterize_triangle */
+    uint64_t point_samples;  /* in-bounds fill_sample calls reached from rasterize_point */
+    uint64_t bin_entries;    /* (primitive, tile) pairs processed */
+} srt_raster_stats_t;
+
+const char* srt_last_error(void);
+
+/* Create / destroy a context on HIP device `device`. */
+int srt_raster_create(int device, srt_raster** out);
+int srt_raster_destroy(srt_raster* r);
+
+/* Size of the render target in pixels and the supersample rate (samples per pixel side, >= 1).
+ * (Re)allocates the device-side state. Equivalent to set_render_target + set_sample_rate. */
+int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32_t sample_rate);
+
+/* Start a new frame: every sample becomes (255,255,255,255) and the pending stream is dropped. */
+int srt_raster_clear(srt_raster* r);
+
+/* Append `n` primitives (host memory) to the frame's ordered stream. May be called repeatedly. */
+int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n);
+
+/* Rasterize the pending stream in order, box-filter resolve, and write width*height RGBA8
+ * (row 0 = top, row-major) into host memory `rgba8_out`. Synchronous: the buffer is complete on return. */
+int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out);
+
+/* Same as srt_raster_resolve but leaves the RGBA8 image in device memory (pointer valid until the next
+ * set_target/destroy) and does not synchronize the stream; used by the resident-input benchmark.
+ * `stream` is a hipStream_t (NULL = the context's own stream). */
+int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgba8_out);
+
+/* Optional: read back the supersample buffer (float RGBA, (width*sr)*(height*sr)*4 floats, row-major)
+ * of the last resolve; parity tests compare it bit-for-bit with super_sample_buffer. */
+int srt_raster_read_samples(srt_raster* r, float* samples_out);
+
+/* Optional: counters of the last resolve (costs an extra device pass). */
+int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out);
+
+/* Block until all work of the context has finished. */
+int srt_raster_sync(srt_raster* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_RASTER_H */

@@ -1,0 +1,491 @@
+// MI355X (gfx950) rasterizer: ordered triangle / point fill into a supersample tile held in LDS,
+// fused box-filter resolve, coalesced RGBA8 write-back.  C ABI: include/srt_raster.h.
+//
+// What is being reproduced (reference paths relative to Assignments/DrawSVG/src/):
+//   rasterize_triangle  software_renderer.cpp:456-516   float bbox, inclusive double loops, sample = corner
+//   inside_triangle     software_renderer.cpp:519-538   fp64 edge functions rounded to fp32, fp32 sign products
+//   fill_sample         software_renderer.cpp:634-658   non-premultiplied "over" on a float RGBA sample in [0,255]
+//   rasterize_point     software_renderer.cpp:272-301   sr x sr block, double -> int truncation
+//   resolve             software_renderer.cpp:573-622   fp32 box sum (x-offset outer, y-offset inner), /sr^2, (uint8_t)
+//
+// Execution model: one wavefront (64 lanes) owns one tile of at most 32x32 samples.  The supersample
+// buffer of the reference (16 B/sample, 256 MiB at 1024^2 x 16 spp) is never materialised in HBM: a
+// tile lives in 16 KiB of LDS from clear to resolve, and only 4 B/pixel leave the CU.  The wave walks
+// the frame's primitive stream IN ORDER (painter's algorithm is order dependent), 64 bounding boxes
+// per step, and rasterizes the overlapping ones into its tile: lane = (x = lane & 31, row parity =
+// lane >> 5), two sample rows per iteration.
+//
+// Numerics: compiled with -ffp-contract=off (the x86-64 reference build has no FMA), IEEE fp32
+// division (hipcc default) and fp32 denormals preserved, so every coverage verdict and every blended
+// sample is bit-identical to the CPU reference.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "srt_common.h"
+
+namespace {
+
+constexpr int TS = 32;  // tile side in samples (max); tile_s = (TS / sr) * sr <= TS
+constexpr int WAVE = 64;
+
+struct RasterParams {
+  uint32_t w, h, sr;
+  uint32_t ssw, ssh;
+  uint32_t tile_px;  // pixels per tile side
+  uint32_t tile_s;   // samples per tile side
+  uint32_t tiles_x, tiles_y;
+  uint32_t nprims;
+};
+
+// stats slots (unsigned long long each)
+enum { ST_TESTS_REF = 0, ST_TESTS_TARGET, ST_FRAGMENTS, ST_POINT_SAMPLES, ST_BIN_ENTRIES, ST_COUNT };
+
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }  // std::min
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }  // std::max
+
+// CMU462::clamp (CMU462/include/CMU462/misc.h:69): std::min(std::max(x, lo), hi)
+__device__ __forceinline__ float clamp255(float x) { return std_min(std_max(x, 0.0f), 255.0f); }
+
+// fill_sample's read-modify-write on one float RGBA sample (software_renderer.cpp:646-650).
+__device__ __forceinline__ float4 blend_over(float4 s, float r, float g, float b, float one_minus_a) {
+  s.x = clamp255((r + one_minus_a * (s.x / 255.0f)) * 255.0f);
+  s.y = clamp255((g + one_minus_a * (s.y / 255.0f)) * 255.0f);
+  s.z = clamp255((b + one_minus_a * (s.z / 255.0f)) * 255.0f);
+  s.w = clamp255((1.0f - (one_minus_a * (1 - (s.w / 255.0f)))) * 255.0f);
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 1: per-primitive sample-space bounding box clipped to the target, int4 {x0,y0,x1,y1}
+// (inclusive; x0 > x1 marks "touches nothing").  Also the reference's own (unclipped) test count.
+// ---------------------------------------------------------------------------------------------
+__global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims, int4* __restrict__ bbox,
+                             unsigned long long* __restrict__ stats) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.nprims) return;
+  const srt_prim p = prims[i];
+  int4 bb = make_int4(1, 1, 0, 0);
+  double lox, hix, loy, hiy;  // inclusive integer-valued ranges the reference loops over
+  bool ok = false;
+  if (p.kind == SRT_PRIM_TRIANGLE) {
+    const float x0 = p.v.tri[0], y0 = p.v.tri[1], x1 = p.v.tri[2], y1 = p.v.tri[3], x2 = p.v.tri[4],
+                y2 = p.v.tri[5];
+    float xmin = floorf(std_min(x0, std_min(x1, x2)));
+    float ymin = floorf(std_min(y0, std_min(y1, y2)));
+    float xmax = ceilf(std_max(x0, std_max(x1, x2)));
+    float ymax = ceilf(std_max(y0, std_max(y1, y2)));
+    const float srf = (float)P.sr;
+    xmin *= srf; xmax *= srf; ymin *= srf; ymax *= srf;  // float *= size_t (cpp:504)
+    lox = xmin; hix = xmax; loy = ymin; hiy = ymax;
+    ok = (lox <= hix) && (loy <= hiy);  // false for NaN
+    if (ok && stats) {
+      const double nx = hix - lox + 1.0, ny = hiy - loy + 1.0;
+      if (nx * ny < 1.8e19) atomicAdd(&stats[ST_TESTS_REF], (unsigned long long)(nx * ny));
+    }
+  } else if (p.kind == SRT_PRIM_POINT) {
+    // fill_sample((int)(x*sr + i), (int)(y*sr + j)) for i,j in [0,sr)   (cpp:296-300)
+    const double fx = p.v.point[0] * (double)P.sr, fy = p.v.point[1] * (double)P.sr;
+    const double lim = 2147483000.0;  // outside int range x86 yields INT_MIN -> rejected by the bounds check
+    ok = (fx > -lim) && (fx < lim) && (fy > -lim) && (fy < lim);
+    lox = trunc(fx); hix = trunc(fx + (double)(P.sr - 1));
+    loy = trunc(fy); hiy = trunc(fy + (double)(P.sr - 1));
+  }
+  if (ok) {
+    const double wx = (double)(P.ssw - 1), wy = (double)(P.ssh - 1);
+    if (hix >= 0.0 && lox <= wx && hiy >= 0.0 && loy <= wy) {
+      bb.x = (int)(lox < 0.0 ? 0.0 : lox);
+      bb.y = (int)(loy < 0.0 ? 0.0 : loy);
+      bb.z = (int)(hix > wx ? wx : hix);
+      bb.w = (int)(hiy > wy ? wy : hiy);
+    }
+  }
+  bbox[i] = bb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 2: one wave per tile.
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
+                                                     const int4* __restrict__ bbox,
+                                                     uint32_t* __restrict__ rgba_out,
+                                                     float4* __restrict__ samples_out,
+                                                     unsigned long long* __restrict__ stats) {
+  __shared__ float4 tile[TS * TS];  // 16 KiB: the tile's slice of super_sample_buffer
+  __shared__ double rowy[TS];       // y / sample_rate for each tile row (fp64 division done once)
+
+  const int lane = threadIdx.x;
+  const int tx = blockIdx.x % P.tiles_x;
+  const int ty = blockIdx.x / P.tiles_x;
+  const int sx0 = tx * (int)P.tile_s, sy0 = ty * (int)P.tile_s;  // tile origin (samples)
+  const int tsw = min((int)P.tile_s, (int)P.ssw - sx0);          // valid extent inside the target
+  const int tsh = min((int)P.tile_s, (int)P.ssh - sy0);
+  const int sx1 = sx0 + tsw - 1, sy1 = sy0 + tsh - 1;
+
+  // clear_target: every sample starts at 255.0f (software_renderer.h:93-98)
+  const float4 white = make_float4(255.0f, 255.0f, 255.0f, 255.0f);
+  for (int i = lane; i < TS * TS; i += WAVE) tile[i] = white;
+  if (lane < TS) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
+
+  const int lx = lane & (TS - 1);
+  const int lrow = lane >> 5;
+  const double px = (double)(sx0 + lx) / (double)P.sr;  // x / sample_rate (cpp:510)
+  __syncthreads();
+
+  unsigned long long n_tests = 0, n_frags = 0, n_pts = 0, n_bins = 0;
+
+  const uint32_t n = P.nprims;
+  for (uint32_t base = 0; base < n; base += WAVE) {
+    const uint32_t idx = base + lane;
+    int4 bb = make_int4(1, 1, 0, 0);
+    if (idx < n) bb = bbox[idx];
+    const bool overlaps = (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
+    unsigned long long mask = __ballot(overlaps);
+
+    while (mask) {  // ascending bit order == stream order
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const uint32_t pidx = __builtin_amdgcn_readfirstlane(base + b);
+      const srt_prim* __restrict__ p = prims + pidx;
+      // rectangle of this primitive inside the tile, tile-local sample coordinates
+      const int rx0 = max(__builtin_amdgcn_readlane(bb.x, b), sx0) - sx0;
+      const int ry0 = max(__builtin_amdgcn_readlane(bb.y, b), sy0) - sy0;
+      const int rx1 = min(__builtin_amdgcn_readlane(bb.z, b), sx1) - sx0;
+      const int ry1 = min(__builtin_amdgcn_readlane(bb.w, b), sy1) - sy0;
+      const float cr = p->rgba[0], cg = p->rgba[1], cb = p->rgba[2];
+      const float one_minus_a = 1 - p->rgba[3];
+      if (STATS) n_bins++;
+
+      if (p->kind == SRT_PRIM_TRIANGLE) {
+        const double ax = (double)p->v.tri[0], ay = (double)p->v.tri[1];
+        const double bx = (double)p->v.tri[2], by = (double)p->v.tri[3];
+        const double cx = (double)p->v.tri[4], cy = (double)p->v.tri[5];
+        const double e0x = bx - ax, e0y = by - ay;  // t0t1
+        const double e1x = cx - bx, e1y = cy - by;  // t1t2
+        const double e2x = ax - cx, e2y = ay - cy;  // t2t0
+        const double d0x = px - ax, d1x = px - bx, d2x = px - cx;
+        const bool xin = (lx >= rx0) && (lx <= rx1);
+        if (STATS) n_tests += (unsigned long long)(rx1 - rx0 + 1) * (unsigned long long)(ry1 - ry0 + 1);
+
+        for (int row = ry0 + lrow; row <= ry1; row += 2) {
+          const double py = rowy[row];
+          const double d0y = py - ay, d1y = py - by, d2y = py - cy;
+          const float c1 = (float)(e0x * d0y - e0y * d0x);
+          const float c2 = (float)(e1x * d1y - e1y * d1x);
+          const float c3 = (float)(e2x * d2y - e2y * d2x);
+          const float p12 = c1 * c2, p23 = c2 * c3, p13 = c1 * c3;
+          const bool ccw = (p12 >= 0) && (p23 >= 0) && (p13 >= 0);
+          const bool cw = (p12 <= 0) && (p23 <= 0) && (p13 <= 0);
+          const bool covered = xin && (ccw || cw);
+          if (covered) {
+            const int si = row * TS + lx;
+            tile[si] = blend_over(tile[si], cr, cg, cb, one_minus_a);
+          }
+          if (STATS) n_frags += __popcll(__ballot(covered));
+        }
+      } else {  // SRT_PRIM_POINT
+        const uint32_t sr = P.sr;
+        const double fx = p->v.point[0] * (double)sr;
+        const double fy = p->v.point[1] * (double)sr;
+        // Distinct (i,j) land on distinct samples unless truncation toward zero folds two of them
+        // onto column/row 0 (fx+i in (-1,0)); then the block must be applied one sample at a time.
+        const bool folds = (fx < 0.0 && fx != trunc(fx) && fx + (double)(sr - 1) > -1.0) ||
+                           (fy < 0.0 && fy != trunc(fy) && fy + (double)(sr - 1) > -1.0);
+        const uint32_t nblk = sr * sr;
+        if (!folds) {
+          for (uint32_t k0 = 0; k0 < nblk; k0 += WAVE) {
+            const uint32_t k = k0 + lane;
+            bool hit = false;
+            int si = 0;
+            if (k < nblk) {
+              const int i = (int)(k / sr), j = (int)(k % sr);
+              const int sx = (int)(fx + i) - sx0, sy = (int)(fy + j) - sy0;
+              hit = (sx >= 0) && (sx < tsw) && (sy >= 0) && (sy < tsh);
+              si = sy * TS + sx;
+            }
+            if (hit) tile[si] = blend_over(tile[si], cr, cg, cb, one_minus_a);
+            if (STATS) n_pts += __popcll(__ballot(hit));
+          }
+        } else {
+          for (uint32_t k = 0; k < nblk; k++) {  // i outer, j inner (cpp:296-297)
+            const int i = (int)(k / sr), j = (int)(k % sr);
+            const int sx = (int)(fx + i) - sx0, sy = (int)(fy + j) - sy0;
+            const bool hit = (sx >= 0) && (sx < tsw) && (sy >= 0) && (sy < tsh);
+            if (hit && lane == 0) {
+              const int si = sy * TS + sx;
+              tile[si] = blend_over(tile[si], cr, cg, cb, one_minus_a);
+            }
+            if (STATS && hit) n_pts++;
+            __syncthreads();
+          }
+        }
+      }
+      __syncthreads();  // LDS RMW of this primitive is visible before the next one starts
+    }
+  }
+  __syncthreads();
+
+  // resolve (cpp:586-619): box sum with x-offset outer / y-offset inner, true division, truncation
+  const int sr = (int)P.sr;
+  const int pw = tsw / sr, ph = tsh / sr;
+  const int px0 = tx * (int)P.tile_px, py0 = ty * (int)P.tile_px;
+  const float denom = (float)((size_t)P.sr * (size_t)P.sr);
+  for (int k = lane; k < pw * ph; k += WAVE) {
+    const int pxl = k % pw, pyl = k / pw;
+    float r = 0, g = 0, bl = 0, a = 0;
+    for (int i = 0; i < sr; ++i) {
+      for (int j = 0; j < sr; ++j) {
+        const float4 s = tile[(pyl * sr + j) * TS + pxl * sr + i];
+        r += s.x; g += s.y; bl += s.z; a += s.w;
+      }
+    }
+    r /= denom; g /= denom; bl /= denom; a /= denom;
+    const uint32_t R = (uint32_t)(uint8_t)(r), G = (uint32_t)(uint8_t)(g), B = (uint32_t)(uint8_t)(bl),
+                   A = (uint32_t)(uint8_t)(a);
+    rgba_out[(size_t)(py0 + pyl) * P.w + (px0 + pxl)] = R | (G << 8) | (B << 16) | (A << 24);
+  }
+
+  if (samples_out) {
+    for (int k = lane; k < tsw * tsh; k += WAVE) {
+      const int c = k % tsw, rr = k / tsw;
+      samples_out[(size_t)(sy0 + rr) * P.ssw + (sx0 + c)] = tile[rr * TS + c];
+    }
+  }
+
+  if (STATS) {
+    if (lane == 0) {
+      atomicAdd(&stats[ST_TESTS_TARGET], n_tests);
+      atomicAdd(&stats[ST_FRAGMENTS], n_frags);
+      atomicAdd(&stats[ST_POINT_SAMPLES], n_pts);
+      atomicAdd(&stats[ST_BIN_ENTRIES], n_bins);
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+struct srt_raster {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  RasterParams P{};
+  bool have_target = false;
+  std::vector<srt_prim> pending;  // host copy of the frame's ordered stream
+  bool dirty = true;              // pending differs from d_prims
+  srt_prim* d_prims = nullptr;
+  int4* d_bbox = nullptr;
+  size_t d_cap = 0;
+  uint32_t* d_rgba = nullptr;
+  float4* d_samples = nullptr;
+  unsigned long long* d_stats = nullptr;
+  bool resolved = false;
+};
+
+namespace {
+
+int upload_stream(srt_raster* r) {
+  const size_t n = r->pending.size();
+  if (n > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32-1 primitives in one frame");
+  if (n > r->d_cap) {
+    if (r->d_prims) SRT_HIP(hipFree(r->d_prims));
+    if (r->d_bbox) SRT_HIP(hipFree(r->d_bbox));
+    r->d_prims = nullptr; r->d_bbox = nullptr;
+    size_t cap = n + n / 2 + 64;
+    SRT_HIP(hipMalloc(&r->d_prims, cap * sizeof(srt_prim)));
+    SRT_HIP(hipMalloc(&r->d_bbox, cap * sizeof(int4)));
+    r->d_cap = cap;
+  }
+  if (n) SRT_HIP(hipMemcpyAsync(r->d_prims, r->pending.data(), n * sizeof(srt_prim), hipMemcpyHostToDevice, r->stream));
+  r->P.nprims = (uint32_t)n;
+  r->dirty = false;
+  return SRT_OK;
+}
+
+// Enqueue setup + tile kernels for the current stream on `s`.
+int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
+  const RasterParams& P = r->P;
+  if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
+  if (P.nprims) {
+    const int bs = 256;
+    raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_bbox,
+                                                                      stats ? r->d_stats : nullptr);
+  }
+  const uint32_t ntiles = P.tiles_x * P.tiles_y;
+  float4* so = dump_samples ? r->d_samples : nullptr;
+  if (stats)
+    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_rgba, so, r->d_stats);
+  else
+    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_rgba, so, nullptr);
+  SRT_HIP(hipGetLastError());
+  r->resolved = true;
+  return SRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srt_raster_create(int device, srt_raster** out) {
+  if (!out) return srt::fail(SRT_ERR_INVALID, "srt_raster_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return srt::fail(SRT_ERR_NO_DEVICE, "no HIP device available (%s); this path has no CPU fallback",
+                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count) return srt::fail(SRT_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+  SRT_HIP(hipSetDevice(device));
+  srt_raster* r = new (std::nothrow) srt_raster();
+  if (!r) return srt::fail(SRT_ERR_INVALID, "out of host memory");
+  r->device = device;
+  if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete r;
+    return srt::fail(SRT_ERR_HIP, "hipStreamCreate failed");
+  }
+  if (hipMalloc(&r->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipStreamDestroy(r->stream);
+    delete r;
+    return srt::fail(SRT_ERR_HIP, "hipMalloc(stats) failed");
+  }
+  *out = r;
+  return SRT_OK;
+}
+
+int srt_raster_destroy(srt_raster* r) {
+  if (!r) return SRT_OK;
+  (void)hipSetDevice(r->device);
+  (void)hipStreamSynchronize(r->stream);
+  (void)hipFree(r->d_prims);
+  (void)hipFree(r->d_bbox);
+  (void)hipFree(r->d_rgba);
+  (void)hipFree(r->d_samples);
+  (void)hipFree(r->d_stats);
+  (void)hipStreamDestroy(r->stream);
+  delete r;
+  return SRT_OK;
+}
+
+int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32_t sample_rate) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_set_target: NULL context");
+  if (width == 0 || height == 0) return srt::fail(SRT_ERR_INVALID, "target must be at least 1x1 (got %ux%u)", width, height);
+  if (sample_rate == 0) return srt::fail(SRT_ERR_INVALID, "sample_rate must be >= 1");
+  if (sample_rate > (uint32_t)TS)
+    return srt::fail(SRT_ERR_UNSUPPORTED, "sample_rate %u > %d is not supported by the tile kernel", sample_rate, TS);
+  if ((uint64_t)width * sample_rate > (1u << 24) || (uint64_t)height * sample_rate > (1u << 24))
+    return srt::fail(SRT_ERR_UNSUPPORTED, "sample grid larger than 2^24 per side");
+  SRT_HIP(hipSetDevice(r->device));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  RasterParams& P = r->P;
+  const bool realloc_px = !r->have_target || P.w != width || P.h != height;
+  P.w = width; P.h = height; P.sr = sample_rate;
+  P.ssw = width * sample_rate; P.ssh = height * sample_rate;
+  P.tile_px = TS / sample_rate;
+  P.tile_s = P.tile_px * sample_rate;
+  P.tiles_x = (width + P.tile_px - 1) / P.tile_px;
+  P.tiles_y = (height + P.tile_px - 1) / P.tile_px;
+  if (realloc_px) {
+    if (r->d_rgba) SRT_HIP(hipFree(r->d_rgba));
+    r->d_rgba = nullptr;
+    SRT_HIP(hipMalloc(&r->d_rgba, (size_t)width * height * 4));
+  }
+  if (r->d_samples) { SRT_HIP(hipFree(r->d_samples)); r->d_samples = nullptr; }
+  r->have_target = true;
+  r->resolved = false;
+  return SRT_OK;
+}
+
+int srt_raster_clear(srt_raster* r) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear: NULL context");
+  r->pending.clear();
+  r->dirty = true;
+  r->resolved = false;
+  return SRT_OK;
+}
+
+int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_submit: NULL context");
+  if (n && !prims) return srt::fail(SRT_ERR_INVALID, "srt_raster_submit: prims is NULL");
+  if (!r->have_target) return srt::fail(SRT_ERR_STATE, "srt_raster_submit before srt_raster_set_target");
+  for (size_t i = 0; i < n; i++)
+    if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT)
+      return srt::fail(SRT_ERR_INVALID, "primitive %zu has unknown kind %u", i, prims[i].kind);
+  try {
+    r->pending.insert(r->pending.end(), prims, prims + n);
+  } catch (...) {
+    return srt::fail(SRT_ERR_INVALID, "out of host memory");
+  }
+  r->dirty = true;
+  return SRT_OK;
+}
+
+int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgba8_out) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve_device: NULL context");
+  if (!r->have_target) return srt::fail(SRT_ERR_STATE, "resolve before srt_raster_set_target");
+  SRT_HIP(hipSetDevice(r->device));
+  hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+  if (r->dirty) {
+    int st = upload_stream(r);
+    if (st != SRT_OK) return st;
+    if (s != r->stream) SRT_HIP(hipStreamSynchronize(r->stream));  // upload went on the context stream
+  }
+  int st = launch_frame(r, s, false, false);
+  if (st != SRT_OK) return st;
+  if (d_rgba8_out) *d_rgba8_out = (const uint8_t*)r->d_rgba;
+  return SRT_OK;
+}
+
+int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out) {
+  if (!rgba8_out) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve: output buffer is NULL");
+  int st = srt_raster_resolve_device(r, nullptr, nullptr);
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  return SRT_OK;
+}
+
+int srt_raster_read_samples(srt_raster* r, float* samples_out) {
+  if (!r || !samples_out) return srt::fail(SRT_ERR_INVALID, "srt_raster_read_samples: NULL argument");
+  if (!r->have_target) return srt::fail(SRT_ERR_STATE, "read_samples before srt_raster_set_target");
+  SRT_HIP(hipSetDevice(r->device));
+  const size_t bytes = (size_t)r->P.ssw * r->P.ssh * sizeof(float4);
+  if (!r->d_samples) SRT_HIP(hipMalloc(&r->d_samples, bytes));
+  if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
+  int st = launch_frame(r, r->stream, true, false);
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipMemcpyAsync(samples_out, r->d_samples, bytes, hipMemcpyDeviceToHost, r->stream));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  return SRT_OK;
+}
+
+int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out) {
+  if (!r || !out) return srt::fail(SRT_ERR_INVALID, "srt_raster_stats: NULL argument");
+  if (!r->have_target) return srt::fail(SRT_ERR_STATE, "stats before srt_raster_set_target");
+  SRT_HIP(hipSetDevice(r->device));
+  if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
+  int st = launch_frame(r, r->stream, false, true);
+  if (st != SRT_OK) return st;
+  unsigned long long h[ST_COUNT];
+  SRT_HIP(hipMemcpyAsync(h, r->d_stats, sizeof h, hipMemcpyDeviceToHost, r->stream));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  out->sample_tests = h[ST_TESTS_REF];
+  out->sample_tests_in_target = h[ST_TESTS_TARGET];
+  out->fragments = h[ST_FRAGMENTS];
+  out->point_samples = h[ST_POINT_SAMPLES];
+  out->bin_entries = h[ST_BIN_ENTRIES];
+  return SRT_OK;
+}
+
+int srt_raster_sync(srt_raster* r) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_sync: NULL context");
+  SRT_HIP(hipSetDevice(r->device));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  return SRT_OK;
+}
+
+}  // extern "C"

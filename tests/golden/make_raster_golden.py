@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generate the rasterizer golden fixtures from the REFERENCE's own code.
+
+Run in the authoring container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_raster_golden.py
+
+For every case the reference's SoftwareRendererImp (compiled from its sources by oracle/Makefile into
+oracle/_ref/libref_raster.so) renders the image; the fixture stores
+  prims      the ordered primitive stream (inputs; from the SVG via our host walk, or synthetic)
+  rgba       the reference's RGBA8 render target            (expected output)
+  ss_sha256  SHA-256 of the reference's float supersample buffer (expected output, hashed: it is 16 B/sample)
+  meta       w, h, sample_rate
+SVG cases additionally assert, at generation time, that feeding `prims` to the reference's private
+rasterize_* functions reproduces draw_svg's output bit for bit (i.e. the host walk is faithful).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _harness as H  # noqa: E402
+from _cases import adversarial_stream  # noqa: E402
+
+SVG_DIR = os.path.join(H.REF_ROOT, "Assignments/DrawSVG/svg")
+
+# name, svg, w, h, sample_rate
+SVG_CASES = [
+    ("cfg1_triangle1_256_ss1", "subdiv/triangle1.svg", 256, 256, 1),   # BASELINE configs[0]
+    ("cfg2_test3_1024_ss4", "basic/test3.svg", 1024, 1024, 4),         # BASELINE configs[1]
+    ("test4_512_ss3", "basic/test4.svg", 512, 512, 3),
+    ("test5_300x200_ss2", "basic/test5.svg", 300, 200, 2),
+    ("test6_256_ss4", "basic/test6.svg", 256, 256, 4),
+    ("test2_lines_256_ss1", "basic/test2.svg", 256, 256, 1),
+    ("prism_alpha_400x300_ss2", "alpha/01_prism.svg", 400, 300, 2),
+    ("buckyball_alpha_256_ss4", "alpha/03_buckyball.svg", 256, 256, 4),
+    ("degenerate1_256_ss2", "hardcore/01_degenerate_square1.svg", 256, 256, 2),
+    ("lion_384_ss3", "illustration/05_lion.svg", 384, 384, 3),
+    ("hexes_320x240_ss1", "illustration/02_hexes.svg", 320, 240, 1),
+]
+
+
+def main():
+    ref = H.ref_raster()
+    assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+    for name, svg, w, h, sr in SVG_CASES:
+        path = os.path.join(SVG_DIR, svg).encode()
+        rgba = np.zeros((h, w, 4), np.uint8)
+        ss = np.zeros((h * sr, w * sr, 4), np.float32)
+        assert ref.ref_raster_render_svg(path, w, h, sr, H.P(rgba), H.P(ss)) == 0
+        cap = 2_000_000
+        prims = np.zeros(cap, H.PRIM_DTYPE)
+        n = ref.ref_raster_svg_stream(path, w, h, sr, H.P(prims), ctypes.c_size_t(cap))
+        assert 0 <= n <= cap
+        prims = prims[:n].copy()
+        rgba2, ss2 = H.ref_raster_prims(prims, w, h, sr, want_samples=True)
+        assert np.array_equal(rgba, rgba2) and np.array_equal(ss.view(np.uint32), ss2.view(np.uint32)), name
+        np.savez_compressed(
+            os.path.join(HERE, f"raster_{name}.npz"),
+            prims=prims, rgba=rgba, ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64),
+            source=np.array(svg),
+        )
+        print(f"{name}: {n} prims ({int((prims['kind'] == 1).sum())} triangles) rgba sha {H.sha(rgba)[:12]}")
+
+    for sr in (1, 2, 3, 4, 5):
+        w, h = 97, 61
+        prims = adversarial_stream(seed=1234 + sr, w=w, h=h)
+        rgba, ss = H.ref_raster_prims(prims, w, h, sr, want_samples=True)
+        np.savez_compressed(
+            os.path.join(HERE, f"raster_adversarial_ss{sr}.npz"),
+            prims=prims, rgba=rgba, ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64),
+            source=np.array("tests/_cases.py:adversarial_stream"),
+        )
+        print(f"adversarial ss{sr}: {len(prims)} prims rgba sha {H.sha(rgba)[:12]}")
+
+
+if __name__ == "__main__":
+    main()
