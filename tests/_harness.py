@@ -90,3 +90,172 @@ def sha(a):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# Path tracer checkers
+# ------------------------------------------------------------------------------------------------
+_ref_pt = None
+
+
+def ref_pt_lib():
+    """The reference's own path tracer (oracle/_ref/libref_pt.so) or None."""
+    global _ref_pt
+    path = os.path.join(ORACLE_DIR, "_ref", "libref_pt.so")
+    if _ref_pt is None and os.path.exists(path):
+        lib = ctypes.CDLL(path)
+        lib.ref_pt_create.restype = ctypes.c_void_p
+        lib.ref_pt_dump_bvh.restype = ctypes.c_long
+        _ref_pt = lib
+    return _ref_pt
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class _SceneFeeder:
+    """Feeds a scenes.py dict through an add_material/add_mesh/add_sphere/commit/set_camera API."""
+
+    def feed(self, scene):
+        for m in scene["materials"]:
+            self._add_material(int(m["type"]), _f32(m["a"]), _f32(m["b"]), float(m["ior"]))
+        for o in scene["objects"]:
+            if o["kind"] == "mesh":
+                self._add_mesh(_f32(o["pos"]), _f32(o["nrm"]), np.ascontiguousarray(o["idx"], np.uint32), _f32(o["T"]),
+                               int(o["material"]), bool(o["is_light"]))
+            else:
+                self._add_sphere(float(o["radius"]), _f32(o["T"]), int(o["material"]))
+        self._commit()
+        c = scene["camera"]
+        self._set_camera(_f32(c["iview"]), float(c["vfov"]), float(c["ar"]))
+
+
+class RefPT(_SceneFeeder):
+    """PT::Pathtracer of the reference, driven through oracle/ref_harness/pt_ref.cpp."""
+
+    def __init__(self, scene, w, h, max_depth=8, use_bvh=True):
+        self.lib = ref_pt_lib()
+        assert self.lib is not None
+        self.w, self.h = w, h
+        self.h_ = ctypes.c_void_p(self.lib.ref_pt_create(w, h, max_depth, int(use_bvh)))
+        self.feed(scene)
+
+    def _add_material(self, t, a, b, ior):
+        assert self.lib.ref_pt_add_material(self.h_, t, P(a), P(b), ctypes.c_float(ior)) >= 0
+
+    def _add_mesh(self, pos, nrm, idx, T, material, is_light):
+        assert self.lib.ref_pt_add_mesh(self.h_, P(pos), P(nrm), len(pos), P(idx), len(idx), P(T), material, int(is_light)) == 0
+
+    def _add_sphere(self, radius, T, material):
+        assert self.lib.ref_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _commit(self):
+        assert self.lib.ref_pt_commit(self.h_) == 0
+
+    def _set_camera(self, iview, vfov, ar):
+        assert self.lib.ref_pt_set_camera(self.h_, P(iview), ctypes.c_float(vfov), ctypes.c_float(ar)) == 0
+
+    def trace_samples(self, seed, xs, ys, ss):
+        xs, ys, ss = (np.ascontiguousarray(a, np.uint32) for a in (xs, ys, ss))
+        out = np.zeros((len(xs), 3), np.float32)
+        draws = np.zeros(len(xs), np.uint32)
+        assert self.lib.ref_pt_trace_samples(self.h_, ctypes.c_uint64(seed), P(xs), P(ys), P(ss), ctypes.c_size_t(len(xs)), P(out), P(draws)) == 0
+        return out, draws
+
+    def epoch(self, seed, sample_base, samples):
+        img = np.zeros((self.h, self.w, 3), np.float32)
+        assert self.lib.ref_pt_epoch(self.h_, ctypes.c_uint64(seed), sample_base, samples, P(img)) == 0
+        return img
+
+    def hit(self, org, dirs, bounds):
+        org, dirs, bounds = _f32(org), _f32(dirs), _f32(bounds)
+        out = np.zeros((len(org), 9), np.float32)
+        assert self.lib.ref_pt_hit(self.h_, P(org), P(dirs), P(bounds), ctypes.c_size_t(len(org)), P(out)) == 0
+        return out
+
+    def dump_bvh(self, which, cap=1 << 22):
+        boxes = np.zeros((cap, 6), np.float32)
+        links = np.zeros((cap, 4), np.uint32)
+        order = np.zeros(cap * 4, np.uint32)
+        n = self.lib.ref_pt_dump_bvh(self.h_, which, P(boxes), P(links), ctypes.c_size_t(cap), P(order))
+        if n < 0:
+            return None
+        return boxes[:n].copy(), links[:n].copy(), order
+
+
+class OraclePT(_SceneFeeder):
+    """oracle/pt_oracle.c driven through ctypes. math_mode 0 = libm (pins against the reference
+    build), 1 = SRT-MATH v1 (what the HIP kernel computes)."""
+
+    def __init__(self, scene, w, h, max_depth=8, use_bvh=True, math_mode=1):
+        self.lib = oracle()
+        self.lib.srt_oracle_pt_create.restype = ctypes.c_void_p
+        self.lib.srt_oracle_pt_dump_bvh.restype = ctypes.c_long
+        self.w, self.h = w, h
+        self.h_ = ctypes.c_void_p(self.lib.srt_oracle_pt_create())
+        self._use_bvh = use_bvh
+        assert self.lib.srt_oracle_pt_set_params(self.h_, w, h, max_depth) == 0
+        self.lib.srt_oracle_pt_set_math(self.h_, math_mode)
+        self.feed(scene)
+
+    def _add_material(self, t, a, b, ior):
+        assert self.lib.srt_oracle_pt_add_material(self.h_, t, P(a), P(b), ctypes.c_float(ior)) >= 0
+
+    def _add_mesh(self, pos, nrm, idx, T, material, is_light):
+        assert self.lib.srt_oracle_pt_add_mesh(self.h_, P(pos), P(nrm), len(pos), P(idx), len(idx), P(T), material, int(is_light)) == 0
+
+    def _add_sphere(self, radius, T, material):
+        assert self.lib.srt_oracle_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _commit(self):
+        rc = self.lib.srt_oracle_pt_commit(self.h_, int(self._use_bvh))
+        assert rc == 0, f"oracle commit failed ({rc})"
+
+    def _set_camera(self, iview, vfov, ar):
+        assert self.lib.srt_oracle_pt_set_camera(self.h_, P(iview), ctypes.c_float(vfov), ctypes.c_float(ar)) == 0
+
+    def set_math(self, mode):
+        self.lib.srt_oracle_pt_set_math(self.h_, mode)
+
+    def trace_samples(self, seed, xs, ys, ss, counters=None):
+        xs, ys, ss = (np.ascontiguousarray(a, np.uint32) for a in (xs, ys, ss))
+        out = np.zeros((len(xs), 3), np.float32)
+        draws = np.zeros(len(xs), np.uint32)
+        rays = np.zeros(len(xs), np.uint32)
+        rc = self.lib.srt_oracle_pt_trace_samples(self.h_, ctypes.c_uint64(seed), P(xs), P(ys), P(ss), ctypes.c_size_t(len(xs)),
+                                                  P(out), P(draws), P(rays), P(counters) if counters is not None else None)
+        assert rc == 0
+        return out, draws, rays
+
+    def epoch(self, seed, sample_base, samples, y0=0, y1=None, img=None, counters=None):
+        if img is None:
+            img = np.zeros((self.h, self.w, 3), np.float32)
+        y1 = self.h if y1 is None else y1
+        rc = self.lib.srt_oracle_pt_epoch_rows(self.h_, ctypes.c_uint64(seed), sample_base, samples, y0, y1, P(img),
+                                               P(counters) if counters is not None else None)
+        assert rc == 0
+        return img
+
+    def hit(self, org, dirs, bounds):
+        org, dirs, bounds = _f32(org), _f32(dirs), _f32(bounds)
+        out = np.zeros((len(org), 9), np.float32)
+        assert self.lib.srt_oracle_pt_hit(self.h_, P(org), P(dirs), P(bounds), ctypes.c_size_t(len(org)), P(out)) == 0
+        return out
+
+    def dump_bvh(self, which, cap=1 << 22):
+        boxes = np.zeros((cap, 6), np.float32)
+        links = np.zeros((cap, 4), np.uint32)
+        order = np.zeros(cap * 4, np.uint32)
+        n = self.lib.srt_oracle_pt_dump_bvh(self.h_, which, P(boxes), P(links), ctypes.c_size_t(cap), P(order))
+        if n < 0:
+            return None
+        return boxes[:n].copy(), links[:n].copy(), order
+
+
+COUNTER_NAMES = ("rays", "box_tests", "objects_entered", "tri_tests", "sphere_tests", "tlas_nodes", "blas_nodes", "light_tri_tests")
+
+
+def oracle_accumulate(acc, epoch, k):
+    oracle().srt_oracle_pt_accumulate(P(acc), P(epoch), ctypes.c_size_t(acc.size), k)
+    return acc

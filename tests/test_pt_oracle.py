@@ -1,0 +1,117 @@
+"""CPU: pin oracle/pt_oracle.c against the golden vectors produced by the reference's own path tracer
+(tests/golden/make_pt_golden.py) and, in the authoring container, against the reference build itself.
+Bar: bit-exact per-sample radiance (NaN == NaN), RNG draw counts, scene.hit records, BVH node arrays."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import _harness as H
+from _cases import pt_sample_list, pt_scene, random_rays, scene_digest
+
+GOLDENS = sorted(glob.glob(os.path.join(H.GOLDEN, "pt_*.npz")))
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def load_case(path):
+    g = np.load(path)
+    w, h, depth, use_bvh, n = (int(x) for x in g["meta"])
+    scene = pt_scene(str(g["scene"]))
+    assert scene_digest(scene) == str(g["scene_sha256"]), "scene description drifted from the fixture"
+    return g, scene, w, h, depth, bool(use_bvh), n, int(g["seed"])
+
+
+def test_goldens_present():
+    names = [os.path.basename(g) for g in GOLDENS]
+    assert "pt_cbox_lambertian_64x64_d8_bvh.npz" in names and "pt_cbox_64x64_d8_bvh.npz" in names
+    assert len(names) >= 7
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "srtmath"])
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(g)[3:-4] for g in GOLDENS])
+def test_oracle_matches_reference_golden(path, math_mode):
+    g, scene, w, h, depth, use_bvh, n, seed = load_case(path)
+    o = H.OraclePT(scene, w, h, depth, use_bvh, math_mode=math_mode)
+    xs, ys, ss = pt_sample_list(seed, w, h, n)
+    rgb, draws, rays = o.trace_samples(seed, xs, ys, ss)
+    assert bits_equal(rgb, g["rgb"]), "per-sample radiance differs from the reference"
+    assert np.array_equal(draws, g["draws"]), "RNG draw ledger differs from the reference"
+    org, d, b = random_rays(seed + 1, 2048)
+    assert bits_equal(o.hit(org, d, b), g["hits"]), "scene.hit differs from the reference"
+    if use_bvh:
+        boxes, links, order = o.dump_bvh(-1)
+        assert bits_equal(boxes, g["tlas_boxes"]) and np.array_equal(links, g["tlas_links"])
+        assert np.array_equal(order[: len(scene["objects"])], g["tlas_order"])
+        for k in range(len(scene["objects"])):
+            if f"blas{k}_boxes" in g:
+                bb, bl, bo = o.dump_bvh(k)
+                assert bits_equal(bb, g[f"blas{k}_boxes"]) and np.array_equal(bl, g[f"blas{k}_links"])
+                assert np.array_equal(bo[: len(g[f"blas{k}_order"])], g[f"blas{k}_order"])
+    if "epoch" in g:
+        ew, eh, spp, base = (int(x) for x in g["epoch_meta"])
+        o2 = H.OraclePT(scene, ew, eh, depth, use_bvh, math_mode=math_mode)
+        assert bits_equal(o2.epoch(seed, base, spp), g["epoch"]), "epoch image differs from the reference"
+
+
+def test_draw_ledger_cornell():
+    """per Lambertian bounce 8 + 2 draws, 2 jitter draws per camera sample."""
+    scene = pt_scene("cbox_lambertian")
+    o = H.OraclePT(scene, 32, 32, 8, True)
+    xs, ys, ss = pt_sample_list(1, 32, 32, 2000)
+    _, draws, rays = o.trace_samples(1, xs, ys, ss)
+    assert ((draws - 2) % 10 == 0).all()          # every shading event is Lambertian here
+    bounces = (draws - 2) // 10
+    assert (rays == 1 + 3 * bounces).all()        # camera ray + (BSDF-direct, MIS-direct, indirect) per event
+    assert bounces.max() <= 8
+
+
+def test_srtmath_matches_libm():
+    """SRT-MATH v2 restates glibc's sinf/cosf: bit-identical on the argument ranges the renderer uses."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(1_000_000, dtype=np.float32) * np.float32(2 * np.pi),
+                        rng.random(1_000_000, dtype=np.float32) * 2 - 1,
+                        np.array([0.0, -0.0, 1e-5, 2 ** -13, 0.785398, 0.7853982, 1.5707964, 3.1415927, 6.2831855], np.float32)])
+    c = np.zeros_like(x)
+    s = np.zeros_like(x)
+    H.oracle().srt_oracle_math_cos_sin(H.P(x), ctypes.c_size_t(len(x)), H.P(c), H.P(s))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    idx = rng.integers(0, len(x), 20000)
+    idx[:9] = np.arange(len(x) - 9, len(x))
+    for i in idx:
+        assert c[i] == np.float32(libm.cosf(float(x[i]))) and s[i] == np.float32(libm.sinf(float(x[i]))), float(x[i])
+
+
+def test_accumulate_running_mean():
+    rng = np.random.default_rng(3)
+    acc = np.zeros(300, np.float32)
+    want = np.zeros(300, np.float32)
+    for k in range(1, 6):
+        e = rng.random(300).astype(np.float32)
+        H.oracle_accumulate(acc, e, k)
+        want = (want + (e - want) * np.float32(1.0 / k)).astype(np.float32)
+    assert np.array_equal(acc, want)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(H.ref_pt_lib() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("name,use_bvh", [("cbox", True), ("cbox_lambertian", False), ("cbox_blob512_glass", True)])
+def test_oracle_matches_reference_build(name, use_bvh):
+    scene = pt_scene(name)
+    w, h = 40, 30
+    ref = H.RefPT(scene, w, h, 8, use_bvh)
+    xs, ys, ss = pt_sample_list(77, w, h, 6000, max_sample=1 << 20)
+    r_rgb, r_draws = ref.trace_samples(123456789, xs, ys, ss)
+    for mode in (0, 1):
+        o = H.OraclePT(scene, w, h, 8, use_bvh, math_mode=mode)
+        rgb, draws, _ = o.trace_samples(123456789, xs, ys, ss)
+        assert bits_equal(rgb, r_rgb) and np.array_equal(draws, r_draws)
+    assert H.ref_pt_lib().ref_pt_unqualified_sqrt_is_double() == 1  # shapes.cpp's sqrt(delta) is fp64
