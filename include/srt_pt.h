@@ -1,0 +1,136 @@
+/*
+ * srt_pt.h — C ABI of the MI355X (gfx950) path-tracer hot path.
+ *
+ * Drop-in boundary for PT::Pathtracer of the reference (paths relative to
+ * /root/reference/Assignments/Scotty3D/src/):
+ *
+ *   srt_pt_scene_begin / add_material / add_mesh / add_sphere / scene_commit
+ *                          <- Pathtracer::build_scene            rays/pathtracer.cpp:66-176
+ *                             (Object ctor rays/object.h:18-34, Tri_Mesh::build student/tri_mesh.cpp:145-170,
+ *                              BVH<>::build student/bvh.inl:35-163 — host side, structure-identical)
+ *   srt_pt_set_camera      <- `camera = cam` in begin_render     rays/pathtracer.cpp:267 (Camera: util/camera.h)
+ *   srt_pt_set_params      <- Pathtracer::set_params             rays/pathtracer.cpp:182-189
+ *   srt_pt_render_epoch    <- Pathtracer::do_trace(samples)      rays/pathtracer.cpp:209-231, i.e. for every pixel
+ *                             trace_pixel (student/pathtracer.cpp:14-40) -> trace (:174-218) ->
+ *                             sample_direct_lighting (:78-172) / sample_indirect_lighting (:42-76) ->
+ *                             BVH<>::hit (student/bvh.inl:227-276), Triangle::hit (student/tri_mesh.cpp:32-111),
+ *                             Sphere::hit (student/shapes.cpp:17-80), BBox::hit (student/bbox.cpp:5-62),
+ *                             BSDF_*::scatter (student/bsdf.cpp:69-154), Samplers (student/samplers.cpp)
+ *   srt_pt_accumulate      <- Pathtracer::accumulate             rays/pathtracer.cpp:195-207
+ *
+ * The epoch loop, progress/cancel bookkeeping and the GUI texture stay in the host class
+ * (soft-rendering-toolsets_amd/host/pathtracer_hip.cpp); see INTEGRATION.md.
+ *
+ * Determinism: util/rand.cpp (thread_local mt19937 seeded from random_device) is replaced by SRT-RNG v1,
+ * a counter-keyed generator re-keyed per (seed, pixel, sample); DESIGN.md states it.  Image rows follow
+ * HDR_Image: row 0 = bottom (util/hdr_image.cpp:54-57).  Matrices are 16 floats in Mat4::data order
+ * (column-major, lib/mat4.h).
+ *
+ * Status codes and srt_last_error(): see srt_raster.h.  No CPU fallback: srt_pt_create fails without a
+ * HIP device.
+ */
+#ifndef SRT_PT_H
+#define SRT_PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "srt_raster.h" /* srt_status, srt_last_error */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Material kinds = the BSDF variants of rays/bsdf.h. */
+enum {
+    SRT_MAT_LAMBERTIAN = 0,    /* a = albedo as passed to BSDF_Lambertian(albedo) (divided by PI_F inside) */
+    SRT_MAT_MIRROR = 1,        /* a = reflectance */
+    SRT_MAT_GLASS = 2,         /* a = transmittance, b = reflectance, ior */
+    SRT_MAT_DIFFUSE_LIGHT = 3, /* a = emitted radiance (Material::emissive()) */
+    SRT_MAT_REFRACT = 4        /* a = transmittance, ior (the reference's scatter is a stub) */
+};
+
+typedef struct srt_pt_material {
+    uint32_t type;
+    float a[3];
+    float b[3];
+    float ior;
+} srt_pt_material;
+
+typedef struct srt_pt srt_pt; /* opaque */
+
+int srt_pt_create(int device, srt_pt** out);
+int srt_pt_destroy(srt_pt* pt);
+
+/* ---- build_scene ---------------------------------------------------------------------------- */
+int srt_pt_scene_begin(srt_pt* pt);
+int srt_pt_add_material(srt_pt* pt, const srt_pt_material* m, uint32_t* index_out);
+/* Object(Tri_Mesh(mesh, use_bvh), id, material, T).  positions/normals: nverts*3 floats; indices: 3 per
+ * triangle.  is_area_light != 0 also appends the Tri_Mesh(mesh, false) copy to the area-light list
+ * (materials of kind DIFFUSE_LIGHT, rays/pathtracer.cpp:105-116). */
+int srt_pt_add_mesh(srt_pt* pt, const float* positions, const float* normals, uint32_t nverts,
+                    const uint32_t* indices, uint32_t nindices, const float trans[16], uint32_t material,
+                    int is_area_light);
+/* Object(Shape(Sphere(radius)), id, material, T). */
+int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t material);
+/* Builds every BVH<Triangle> (leaf size 4) and the BVH<Object> (leaf size 1) exactly as the reference
+ * does — or the List<> forms when use_bvh == 0 — flattens them and uploads the scene. */
+int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
+
+int srt_pt_set_camera(srt_pt* pt, const float iview[16], float vert_fov_deg, float aspect_ratio);
+int srt_pt_set_params(srt_pt* pt, uint32_t width, uint32_t height, uint32_t max_depth);
+
+/* ---- image-tile sharding (one process per GPU) ---------------------------------------------------
+ * The image is cut into tile_w x tile_h tiles numbered row-major; rank r of `world` renders the tiles
+ * t with t % world == r.  Defaults: 32 x 32, rank 0, world 1. */
+int srt_pt_set_tiling(srt_pt* pt, uint32_t tile_w, uint32_t tile_h, uint32_t rank, uint32_t world);
+/* Number of tiles this rank renders / the per-rank capacity every rank pads to (ceil(ntiles / world)),
+ * and floats per tile (tile_w * tile_h * 3). */
+int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank, uint32_t* floats_per_tile);
+
+/* ---- do_trace ------------------------------------------------------------------------------------
+ * One epoch: for every pixel of this rank's tiles, the mean over the VALID samples
+ * sample_base .. sample_base + samples - 1 of trace_pixel (invalid = non-finite, dropped as in
+ * rays/pathtracer.cpp:219-222).
+ * Host form: rgb_out is a full width*height*3 float image (row 0 = bottom); only this rank's pixels are
+ * written.  Synchronous. */
+int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_t samples, float* rgb_out);
+/* Device form: d_tiles_out is DEVICE memory of tiles_per_rank * floats_per_tile floats, tile-major
+ * (local tile k = global tile rank + k * world); enqueued on `stream` (hipStream_t, NULL = context
+ * stream), not synchronized.  This is the buffer the RCCL gather moves. */
+int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples,
+                               float* d_tiles_out);
+/* d_gathered: DEVICE, world * tiles_per_rank * floats_per_tile floats as gathered on the root (rank-major).
+ * Scatters the tiles into the width*height*3 DEVICE image d_image (row 0 = bottom). */
+int srt_pt_untile_device(srt_pt* pt, void* stream, const float* d_gathered, float* d_image);
+/* Pathtracer::accumulate on DEVICE buffers of nfloats: acc += (epoch - acc) * (1.0f / accumulator_samples). */
+int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, const float* d_epoch, size_t nfloats,
+                             uint32_t accumulator_samples);
+
+/* Rays (scene.hit calls) and camera samples traced by this context since the last reset. */
+int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);
+
+/* ---- parity / inspection -------------------------------------------------------------------------- */
+/* trace_pixel for explicit (x, y, sample) triples (host arrays of n).  rgb_out: 3 floats per sample;
+ * draws_out / rays_out (nullable): RNG draws and scene.hit calls of that sample. */
+int srt_pt_trace_samples(srt_pt* pt, uint64_t seed, const uint32_t* xs, const uint32_t* ys, const uint32_t* ss,
+                         size_t n, float* rgb_out, uint32_t* draws_out, uint32_t* rays_out);
+/* scene.hit for explicit rays.  out9: {hit, distance, position[3], normal[3], material} per ray (Trace). */
+int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float* bounds, size_t n, float* out9);
+/* Host-side BVH arrays after commit.  which = -1: the BVH<Object> (order = 1-based insertion index of the
+ * objects in BVH primitive order); which >= 0: the BVH<Triangle> of the which-th BVH<Object> primitive
+ * (order = first vertex index of each triangle in BVH primitive order).  boxes: 6 floats per node,
+ * links: {start, size, l, r} per node.  Returns the node count or a negative status. */
+long srt_pt_dump_bvh(srt_pt* pt, int which, float* boxes, uint32_t* links, size_t cap, uint32_t* order);
+/* Traversal counters of the LAST srt_pt_trace_samples call (an instrumented launch):
+ * {rays, box_tests, objects_entered, tri_tests, sphere_tests, tlas_nodes, blas_nodes, light_tri_tests}. */
+int srt_pt_counters(srt_pt* pt, uint64_t out[8]);
+/* cosf/sinf of the kernel (SRT-MATH v2) for n host floats; parity tests compare them with glibc. */
+int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, float* sin_out);
+
+int srt_pt_sync(srt_pt* pt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_PT_H */

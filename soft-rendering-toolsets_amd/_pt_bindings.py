@@ -1,13 +1,234 @@
-"""ctypes bindings of include/srt_pt.h (path tracer). Filled in with the path-tracer milestone."""
+"""ctypes bindings of include/srt_pt.h and a mirror of PT::Pathtracer's public surface
+(/root/reference/Assignments/Scotty3D/src/rays/pathtracer.h:24-40).  Plumbing only: every number
+is produced by the HIP kernels behind the C ABI."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int, c_long, c_size_t, c_uint32, c_uint64, c_void_p
+
+import numpy as np
 
 
-def bind(lib):
-    pass
+class PtMaterial(ctypes.Structure):
+    _fields_ = [("type", c_uint32), ("a", c_float * 3), ("b", c_float * 3), ("ior", c_float)]
 
 
-class Scene:  # placeholder until the path-tracer milestone lands
-    pass
+COUNTER_NAMES = ("rays", "box_tests", "objects_entered", "tri_tests", "sphere_tests", "tlas_nodes", "blas_nodes",
+                 "light_tri_tests")
 
 
-class Pathtracer:  # placeholder until the path-tracer milestone lands
-    pass
+def bind(lib: ctypes.CDLL) -> None:
+    lib.srt_pt_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.srt_pt_destroy.argtypes = [c_void_p]
+    lib.srt_pt_scene_begin.argtypes = [c_void_p]
+    lib.srt_pt_add_material.argtypes = [c_void_p, POINTER(PtMaterial), POINTER(c_uint32)]
+    lib.srt_pt_add_mesh.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_int]
+    lib.srt_pt_add_sphere.argtypes = [c_void_p, c_float, c_void_p, c_uint32]
+    lib.srt_pt_scene_commit.argtypes = [c_void_p, c_int]
+    lib.srt_pt_set_camera.argtypes = [c_void_p, c_void_p, c_float, c_float]
+    lib.srt_pt_set_params.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32]
+    lib.srt_pt_set_tiling.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]
+    lib.srt_pt_tile_info.argtypes = [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]
+    lib.srt_pt_render_epoch.argtypes = [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]
+    lib.srt_pt_render_epoch_device.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]
+    lib.srt_pt_untile_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.srt_pt_accumulate_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint32]
+    lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
+    lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
+    lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_dump_bvh.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_dump_bvh.restype = c_long
+    lib.srt_pt_counters.argtypes = [c_void_p, c_void_p]
+    lib.srt_pt_math_cos_sin.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
+    lib.srt_pt_sync.argtypes = [c_void_p]
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Scene:
+    """A scene description (see scenes.py): materials, objects, camera — the inputs of build_scene."""
+
+    def __init__(self, description: dict):
+        self.description = description
+
+
+class Pathtracer:
+    """Mirror of PT::Pathtracer for the HIP path.
+
+    Reference call sequence (gui/widgets.cpp:921-967): set_params(w, h, samples, depth, use_bvh) ->
+    begin_render(scene, camera) -> poll in_progress()/progress() -> get_output().  Here begin_render is
+    synchronous (the C++ drop-in keeps the reference's asynchronous worker); the epoch
+    scheme is the reference's: samples_per_epoch = max(1, n / (n_threads * 10)), running mean of epoch
+    means (rays/pathtracer.cpp:250-280, 195-207).
+
+    device = -1 creates a host-only context: scene assembly and BVH inspection work, rendering raises.
+    """
+
+    def __init__(self, device: int = 0, n_threads: int | None = None):
+        from . import SrtError, _check, load_library
+
+        self._SrtError, self._check = SrtError, _check
+        self._lib = load_library()
+        self._ctx = c_void_p()
+        _check(self._lib, self._lib.srt_pt_create(device, ctypes.byref(self._ctx)))
+        self.n_threads = n_threads or os.cpu_count() or 1
+        self.out_w = self.out_h = 0
+        self.n_samples = 0
+        self.max_depth = 8
+        self.scene_use_bvh = True
+        self.accumulator = None
+        self.accumulator_samples = 0
+        self.total_epochs = self.completed_epochs = 0
+        self.seed = 0
+        self._sample_cursor = 0
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.srt_pt_destroy(self._ctx)
+            self._ctx = c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference surface -------------------------------------------------------------------------
+    def set_params(self, w: int, h: int, pixel_samples: int, depth: int, use_bvh: bool) -> None:
+        self.out_w, self.out_h, self.n_samples, self.max_depth = int(w), int(h), int(pixel_samples), int(depth)
+        self.scene_use_bvh = bool(use_bvh)
+        self.accumulator = np.zeros((self.out_h, self.out_w, 3), np.float32)
+        self._check(self._lib, self._lib.srt_pt_set_params(self._ctx, self.out_w, self.out_h, self.max_depth))
+
+    def set_samples(self, samples: int) -> None:
+        self.n_samples = int(samples)
+
+    def build_scene(self, scene) -> None:
+        d = scene.description if isinstance(scene, Scene) else scene
+        L = self._lib
+        self._check(L, L.srt_pt_scene_begin(self._ctx))
+        for m in d["materials"]:
+            pm = PtMaterial(int(m["type"]), (c_float * 3)(*[float(v) for v in m["a"]]), (c_float * 3)(*[float(v) for v in m["b"]]),
+                            float(m["ior"]))
+            self._check(L, L.srt_pt_add_material(self._ctx, ctypes.byref(pm), None))
+        for o in d["objects"]:
+            T = _f32(o["T"])
+            if o["kind"] == "mesh":
+                pos, nrm = _f32(o["pos"]), _f32(o["nrm"])
+                idx = np.ascontiguousarray(o["idx"], np.uint32)
+                self._check(L, L.srt_pt_add_mesh(self._ctx, _p(pos), _p(nrm), len(pos), _p(idx), len(idx), _p(T),
+                                                 int(o["material"]), int(bool(o["is_light"]))))
+            else:
+                self._check(L, L.srt_pt_add_sphere(self._ctx, float(o["radius"]), _p(T), int(o["material"])))
+        self._check(L, L.srt_pt_scene_commit(self._ctx, int(self.scene_use_bvh)))
+
+    def set_camera(self, camera: dict) -> None:
+        iv = _f32(camera["iview"])
+        self._check(self._lib, self._lib.srt_pt_set_camera(self._ctx, _p(iv), float(camera["vfov"]), float(camera["ar"])))
+
+    def begin_render(self, scene, camera: dict | None = None, add_samples: bool = False, samples_per_epoch: int | None = None) -> None:
+        d = scene.description if isinstance(scene, Scene) else scene
+        spe = samples_per_epoch or max(1, self.n_samples // (self.n_threads * 10))
+        self.total_epochs = self.n_samples // spe + (1 if self.n_samples % spe else 0)
+        self.completed_epochs = 0
+        if not add_samples:
+            self.accumulator[...] = 0
+            self.accumulator_samples = 0
+            self._sample_cursor = 0
+            self.build_scene(d)
+        self.set_camera(camera or d["camera"])
+        s = 0
+        while s < self.n_samples:
+            n = min(spe, self.n_samples - s)
+            epoch = self.render_epoch(self.seed, self._sample_cursor, n)
+            self.accumulate(epoch)
+            self._sample_cursor += n
+            self.completed_epochs += 1
+            s += n
+
+    def accumulate(self, sample: np.ndarray) -> None:
+        """rays/pathtracer.cpp:195-207 on the host copy (the device form is srt_pt_accumulate_device)."""
+        self.accumulator_samples += 1
+        inv = np.float32(1.0) / np.float32(self.accumulator_samples)
+        self.accumulator += ((sample - self.accumulator).astype(np.float32) * inv).astype(np.float32)
+
+    def in_progress(self) -> bool:
+        return self.completed_epochs < self.total_epochs
+
+    def progress(self) -> float:
+        return self.completed_epochs / self.total_epochs if self.total_epochs else 0.0
+
+    def get_output(self) -> np.ndarray:
+        return self.accumulator
+
+    def cancel(self) -> None:
+        self.completed_epochs = self.total_epochs = 0
+
+    # -- C-ABI steps ---------------------------------------------------------------------------------
+    def set_tiling(self, tile_w: int, tile_h: int, rank: int, world: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_set_tiling(self._ctx, tile_w, tile_h, rank, world))
+
+    def tile_info(self):
+        a, b, c = c_uint32(), c_uint32(), c_uint32()
+        self._check(self._lib, self._lib.srt_pt_tile_info(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def render_epoch(self, seed: int, sample_base: int, samples: int, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.zeros((self.out_h, self.out_w, 3), np.float32)
+        self._check(self._lib, self._lib.srt_pt_render_epoch(self._ctx, seed, sample_base, samples, _p(out)))
+        return out
+
+    def render_epoch_device(self, stream: int, seed: int, sample_base: int, samples: int, d_tiles_out: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_render_epoch_device(self._ctx, c_void_p(stream), seed, sample_base, samples,
+                                                                    c_void_p(d_tiles_out)))
+
+    def untile_device(self, stream: int, d_gathered: int, d_image: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_untile_device(self._ctx, c_void_p(stream), c_void_p(d_gathered), c_void_p(d_image)))
+
+    def accumulate_device(self, stream: int, d_acc: int, d_epoch: int, nfloats: int, k: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_accumulate_device(self._ctx, c_void_p(stream), c_void_p(d_acc), c_void_p(d_epoch), nfloats, k))
+
+    def trace_samples(self, seed: int, xs, ys, ss):
+        xs, ys, ss = (np.ascontiguousarray(a, np.uint32) for a in (xs, ys, ss))
+        rgb = np.zeros((len(xs), 3), np.float32)
+        draws = np.zeros(len(xs), np.uint32)
+        rays = np.zeros(len(xs), np.uint32)
+        self._check(self._lib, self._lib.srt_pt_trace_samples(self._ctx, seed, _p(xs), _p(ys), _p(ss), len(xs), _p(rgb), _p(draws), _p(rays)))
+        return rgb, draws, rays
+
+    def counters(self) -> dict:
+        out = np.zeros(8, np.uint64)
+        self._check(self._lib, self._lib.srt_pt_counters(self._ctx, _p(out)))
+        return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
+
+    def hit(self, org, dirs, bounds) -> np.ndarray:
+        org, dirs, bounds = _f32(org), _f32(dirs), _f32(bounds)
+        out = np.zeros((len(org), 9), np.float32)
+        self._check(self._lib, self._lib.srt_pt_hit(self._ctx, _p(org), _p(dirs), _p(bounds), len(org), _p(out)))
+        return out
+
+    def dump_bvh(self, which: int, cap: int = 1 << 22):
+        boxes = np.zeros((cap, 6), np.float32)
+        links = np.zeros((cap, 4), np.uint32)
+        order = np.zeros(cap * 4, np.uint32)
+        n = self._lib.srt_pt_dump_bvh(self._ctx, which, _p(boxes), _p(links), cap, _p(order))
+        if n < 0:
+            raise self._SrtError(int(n), self._lib.srt_last_error().decode())
+        return boxes[:n].copy(), links[:n].copy(), order
+
+    def math_cos_sin(self, x):
+        x = _f32(x)
+        c, s = np.zeros_like(x), np.zeros_like(x)
+        self._check(self._lib, self._lib.srt_pt_math_cos_sin(self._ctx, _p(x), len(x), _p(c), _p(s)))
+        return c, s
+
+    def sync(self) -> None:
+        self._check(self._lib, self._lib.srt_pt_sync(self._ctx))

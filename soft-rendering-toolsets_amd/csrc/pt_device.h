@@ -1,0 +1,268 @@
+// Device-side arithmetic of the path tracer: vector / matrix helpers with the reference's operation
+// order, SRT-RNG v1, SRT-MATH v2 (glibc's sincosf algorithm), primitive intersection.
+//
+// Everything here must round exactly like the x86-64 build of the reference: fp32 throughout, fp64
+// only where the reference widens (unqualified sqrt/pow), no FMA contraction (-ffp-contract=off),
+// IEEE divide/sqrt (hipcc default), denormals preserved.  Reference paths are relative to
+// /root/reference/Assignments/Scotty3D/src/.
+#ifndef SRT_PT_DEVICE_H
+#define SRT_PT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "pt_scene.h"
+
+namespace srt {
+
+#define SRT_DEV __device__ __forceinline__
+
+constexpr float kEps = 0.00001f;                                   // EPS_F, lib/mathlib.h:16
+constexpr float kPi = 3.14159265358979323846264338327950288f;      // PI_F,  lib/mathlib.h:17
+
+struct V3 { float x, y, z; };
+struct Spec { float r, g, b; };
+struct Ray { V3 o, d; float b0, b1; };
+
+SRT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+SRT_DEV V3 v3p(const float* p) { return v3(p[0], p[1], p[2]); }
+SRT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SRT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SRT_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }   // Vec3*float == float*Vec3
+SRT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+SRT_DEV V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+SRT_DEV float dot(V3 l, V3 r) { return l.x * r.x + l.y * r.y + l.z * r.z; }
+SRT_DEV V3 cross(V3 l, V3 r) { return v3(l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x); }
+SRT_DEV float norm2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+SRT_DEV float norm(V3 a) { return sqrtf(norm2(a)); }
+SRT_DEV V3 unit(V3 a) { const float n = norm(a); return v3(a.x / n, a.y / n, a.z / n); }
+SRT_DEV float std_min(float a, float b) { return (b < a) ? b : a; }
+SRT_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
+
+SRT_DEV Spec spec(float r, float g, float b) { Spec s; s.r = r; s.g = g; s.b = b; return s; }
+SRT_DEV Spec operator+(Spec a, Spec b) { return spec(a.r + b.r, a.g + b.g, a.b + b.b); }
+SRT_DEV Spec operator-(Spec a, Spec b) { return spec(a.r - b.r, a.g - b.g, a.b - b.b); }
+SRT_DEV Spec operator*(Spec a, Spec b) { return spec(a.r * b.r, a.g * b.g, a.b * b.b); }
+SRT_DEV Spec operator*(Spec a, float s) { return spec(a.r * s, a.g * s, a.b * s); }
+SRT_DEV float luma(Spec a) { return 0.2126f * a.r + 0.7152f * a.g + 0.0722f * a.b; }   // lib/spectrum.h:111
+SRT_DEV bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+SRT_DEV bool valid(Spec a) { return finite_f(a.r) && finite_f(a.g) && finite_f(a.b); }  // lib/spectrum.h:115
+
+// Mat4 * Vec3 (projective, lib/mat4.h:125-131) and Mat4::rotate (w = 0; the 0*col3 term is kept).
+SRT_DEV V3 mat_point(const Mat4& m, V3 v) {
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) o[j] = ((m.c[0][j] * v.x + m.c[1][j] * v.y) + m.c[2][j] * v.z) + m.c[3][j] * 1.0f;
+  return v3(o[0] / o[3], o[1] / o[3], o[2] / o[3]);
+}
+SRT_DEV V3 mat_rotate(const Mat4& m, V3 v) {
+  float o[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) o[j] = ((m.c[0][j] * v.x + m.c[1][j] * v.y) + m.c[2][j] * v.z) + m.c[3][j] * 0.0f;
+  return v3(o[0], o[1], o[2]);
+}
+// m.T().rotate(v): component j = v.x*m[j][0] + v.y*m[j][1] + v.z*m[j][2] + 0*m[j][3]
+SRT_DEV V3 mat_rotate_transposed(const Mat4& m, V3 v) {
+  float o[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) o[j] = ((m.c[j][0] * v.x + m.c[j][1] * v.y) + m.c[j][2] * v.z) + m.c[j][3] * 0.0f;
+  return v3(o[0], o[1], o[2]);
+}
+
+// Ray::transform (lib/ray.h:31-37)
+SRT_DEV void ray_transform(Ray& r, const Mat4& m) {
+  r.o = mat_point(m, r.o);
+  r.d = mat_rotate(m, r.d);
+  const float d = norm(r.d);
+  r.b0 *= d;
+  r.b1 *= d;
+  r.d = r.d / d;
+}
+SRT_DEV Ray make_ray(V3 o, V3 d, float b0, float b1) {  // explicit Ray(point, dir, bounds): dir.unit()
+  Ray r; r.o = o; r.d = unit(d); r.b0 = b0; r.b1 = b1; return r;
+}
+SRT_DEV V3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }
+
+// ---------------------------------------------------------------------------------------------------
+// SRT-RNG v1 (replaces util/rand.cpp:13-25): PCG32 XSH-RR keyed by splitmix64(seed, pixel, sample)
+// ---------------------------------------------------------------------------------------------------
+struct Rng {
+  uint64_t state, inc;
+  uint32_t draws;
+  SRT_DEV void key(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    const uint64_t k = ((uint64_t)pixel << 32) | sample;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (k + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    inc = (k << 1) | 1;
+    state = z * 6364136223846793005ull + inc;
+    draws = 0;
+  }
+  SRT_DEV uint32_t next() {
+    const uint64_t old = state;
+    state = old * 6364136223846793005ull + inc;
+    const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    const uint32_t rot = (uint32_t)(old >> 59);
+    draws++;
+    return (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  SRT_DEV float unit() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+  SRT_DEV int integer(int lo, int hi) { return lo + (int)(((uint64_t)next() * (uint64_t)(uint32_t)(hi - lo)) >> 32); }
+  SRT_DEV bool coin(float p) { return unit() < p; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// SRT-MATH v2: glibc 2.35 sinf/cosf (sysdeps/ieee754/flt-32/{s_sinf,s_cosf}.c, sincosf.h, sincosf_data.c)
+// evaluated in fp64 without FMA.  Valid for |x| < 120 (the renderer uses [0, 2pi] and [-1, 1]).
+// ---------------------------------------------------------------------------------------------------
+SRT_DEV float sincos_poly(double x, double x2, bool negated_cos_table, int n) {
+  const double sgn = negated_cos_table ? -1.0 : 1.0;  // table[1] negates the cosine coefficients only
+  if ((n & 1) == 0) {
+    const double x3 = x * x2;
+    const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * -0x1.555545995a603p-3;
+    return (float)(s + x7 * s1);
+  } else {
+    const double x4 = x2 * x2;
+    const double c2 = (sgn * -0x1.6c087e89a359dp-10) + x2 * (sgn * 0x1.99343027bf8c3p-16);
+    const double c1 = (sgn * 0x1p0) + x2 * (sgn * -0x1.ffffffd0c621cp-2);
+    const double x6 = x4 * x2;
+    const double c = c1 + x4 * (sgn * 0x1.55553e1068f19p-5);
+    return (float)(c + x6 * c2);
+  }
+}
+SRT_DEV float srt_sincosf(float y, int want_cos) {
+  double x = (double)y;
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+  if (top < 0x3f4u) {                      // abstop12(y) < abstop12(pi/4 = 0x1.921FB6p-1f)
+    if (top < 0x398u) return want_cos ? 1.0f : y;   // |y| < 2^-12
+    return sincos_poly(x, x * x, false, want_cos);
+  }
+  if (top < 0x42fu) {                      // abstop12(120.0f)
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const int q = n & 3;
+    const double s = (q == 1 || q == 2) ? -1.0 : 1.0;
+    return sincos_poly(x * s, x * x, (n & 2) != 0, n ^ want_cos);
+  }
+  return __uint_as_float(0x7fc00000u);
+}
+SRT_DEV float srt_cosf(float x) { return srt_sincosf(x, 1); }
+SRT_DEV float srt_sinf(float x) { return srt_sincosf(x, 0); }
+// (float)pow(x, 2) / (float)pow(1 - c, 5) with the float promoted to double (student/bsdf.cpp:17-21,47,150)
+SRT_DEV double pow2d(float x) { return (double)x * (double)x; }
+SRT_DEV double pow5d(float x) { const double d = (double)x, d2 = d * d, d4 = d2 * d2; return d4 * d; }
+
+// ---------------------------------------------------------------------------------------------------
+// BBox::hit (student/bbox.cpp:5-62): line/slab test; `times` is only narrowed when tmin/tmax fall inside it.
+// ---------------------------------------------------------------------------------------------------
+SRT_DEV bool box_hit(const Node& nd, const Ray& ray, float& tx, float& ty) {
+  const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
+  const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
+  float tmin = ((sx ? nd.mx[0] : nd.mn[0]) - ray.o.x) * ix;
+  float tmax = ((sx ? nd.mn[0] : nd.mx[0]) - ray.o.x) * ix;
+  const float tymin = ((sy ? nd.mx[1] : nd.mn[1]) - ray.o.y) * iy;
+  const float tymax = ((sy ? nd.mn[1] : nd.mx[1]) - ray.o.y) * iy;
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  const float tzmin = ((sz ? nd.mx[2] : nd.mn[2]) - ray.o.z) * iz;
+  const float tzmax = ((sz ? nd.mn[2] : nd.mx[2]) - ray.o.z) * iz;
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  if (tmin >= tx && tmin <= ty) tx = tmin;
+  if (tmax >= tx && tmax <= ty) ty = tmax;
+  return true;
+}
+
+// Triangle::hit (student/tri_mesh.cpp:32-111) on the precomputed {p0, e1, e2}.  Returns hit and, when hit,
+// distance = |t*d| and the barycentric triple (u, v, t).
+struct TriHit { bool hit; float dist, u, v, t; };
+SRT_DEV TriHit tri_hit(const Tri& g, const Ray& ray) {
+  TriHit h;
+  h.hit = true; h.dist = FLT_MIN; h.u = h.v = h.t = 0.0f;
+  const V3 e1 = v3p(g.e1), e2 = v3p(g.e2);
+  const V3 s = ray.o - v3p(g.p0);
+  const V3 e1xd = cross(e1, ray.d);
+  const float det = dot(e1xd, e2);
+  if (det != 0) {
+    const V3 sxe2 = cross(s, e2);
+    const float nu = -1.0f * dot(sxe2, ray.d);
+    const float nv = dot(e1xd, s);
+    const float nt = -1.0f * dot(sxe2, e1);
+    h.u = nu / det; h.v = nv / det; h.t = nt / det;
+    if (h.u < 0 || h.v < 0 || (1.0f - h.u - h.v) < 0 || h.t < 0) h.hit = false;
+    h.dist = fabsf(norm(ray.d * h.t));
+    if (h.dist < ray.b0 || h.dist > ray.b1) h.hit = false;
+  } else {
+    h.hit = false;
+  }
+  return h;
+}
+
+// Sphere::hit (student/shapes.cpp:17-80).  The reference's unqualified sqrt(delta) is the double overload,
+// so the numerator sum and the quotient are fp64 before narrowing to t1/t2.
+struct SphHit { bool hit; float t; };
+SRT_DEV SphHit sphere_hit(float radius, const Ray& ray) {
+  SphHit h; h.hit = true; h.t = 0.0f;
+  const float a = norm2(ray.d);
+  const float b = 2.0f * dot(ray.o, ray.d);
+  const float c = norm2(ray.o) - radius * radius;
+  const float delta = b * b - 4.0f * a * c;
+  if (delta > 0) {
+    const double m2od = (double)((-2.0f) * dot(ray.o, ray.d));
+    const double sq = sqrt((double)delta);
+    const double den = (double)(2.0f * norm2(ray.d));
+    const float t1 = (float)((m2od + sq) / den);
+    const float t2 = (float)((m2od - sq) / den);
+    bool v1 = !(t1 < 0), v2 = !(t2 < 0);
+    const float d1 = fabsf(norm(ray.d * t1));
+    const float d2 = fabsf(norm(ray.d * t2));
+    if (d1 < ray.b0 || d1 > ray.b1) v1 = false;
+    if (d2 < ray.b0 || d2 > ray.b1) v2 = false;
+    if (v1 && v2) h.t = std_min(t1, t2);
+    else if (!v1 && !v2) h.hit = false;
+    else h.t = v1 ? t1 : t2;
+  } else if (delta == 0) {
+    h.t = ((-2.0f) * dot(ray.o, ray.d)) / (2.0f * norm2(ray.d));
+  } else {
+    h.hit = false;
+  }
+  return h;
+}
+
+// Mat4::rotate_to (lib/mat4.h:353-367): columns x, dir, z of the shading frame.
+struct Frame { V3 x, y, z; };
+SRT_DEV Frame rotate_to(V3 dir) {
+  const float n = norm(dir);
+  dir.x /= n; dir.y /= n; dir.z /= n;
+  Frame f;
+  if (fabsf(dir.y - 1.0f) < kEps) { f.x = v3(1, 0, 0); f.y = v3(0, 1, 0); f.z = v3(0, 0, 1); return f; }
+  if (fabsf(dir.y + 1.0f) < kEps) { f.x = v3(1, 0, 0); f.y = v3(0, -1, 0); f.z = v3(0, 0, 1); return f; }
+  f.x = unit(cross(dir, v3(0.0f, 1.0f, 0.0f)));
+  f.z = unit(cross(f.x, dir));
+  f.y = dir;
+  return f;
+}
+// object_to_world.rotate(v): v.x*col0 + v.y*col1 + v.z*col2 + 0*col3 (col3 = (0,0,0,1))
+SRT_DEV V3 frame_to_world(const Frame& f, V3 v) {
+  return v3(((f.x.x * v.x + f.y.x * v.y) + f.z.x * v.z) + 0.0f * 0.0f,
+            ((f.x.y * v.x + f.y.y * v.y) + f.z.y * v.z) + 0.0f * 0.0f,
+            ((f.x.z * v.x + f.y.z * v.y) + f.z.z * v.z) + 0.0f * 0.0f);
+}
+// world_to_object = object_to_world.T(); its columns are (x.x, y.x, z.x, 0) ...
+SRT_DEV V3 frame_to_local(const Frame& f, V3 v) {
+  return v3(((f.x.x * v.x + f.x.y * v.y) + f.x.z * v.z) + 0.0f * 0.0f,
+            ((f.y.x * v.x + f.y.y * v.y) + f.y.z * v.z) + 0.0f * 0.0f,
+            ((f.z.x * v.x + f.z.y * v.y) + f.z.z * v.z) + 0.0f * 0.0f);
+}
+
+}  // namespace srt
+
+#endif
