@@ -20,7 +20,7 @@
 #include "svg.h"
 #include "viewport.h"
 
-#include "software_renderer_hip.h"  // our drop-in class, used here only for its host-side element walk
+#include "svg_stream.h"  // the host half of our drop-in (no device dependency)
 #include "srt_raster.h"
 
 using namespace CMU462;
@@ -64,16 +64,13 @@ int ref_raster_render_svg(const char* path, uint32_t w, uint32_t h, uint32_t sr,
   return 0;
 }
 
-// The ordered primitive stream our host walk (SoftwareRendererHIP::build_stream) emits for the same
+// The ordered primitive stream our host walk (SvgStreamBuilder::build) emits for the same
 // SVG / framing.  Returns the number of primitives (writes at most cap of them), <0 on error.
 long ref_raster_svg_stream(const char* path, uint32_t w, uint32_t h, uint32_t sr, srt_prim* out, size_t cap) {
   SVG* svg = new SVG();
   if (SVGParser::load(path, svg) < 0) return -1;
-  SoftwareRendererHIP* ren = new SoftwareRendererHIP(0, /*connect_device=*/false);
-  ren->set_render_target(nullptr, w, h);
-  ren->set_sample_rate(sr);
-  ren->set_svg_2_screen(initial_svg_2_screen(*svg, w, h));
-  const std::vector<srt_prim>& s = ren->build_stream(*svg);
+  SvgStreamBuilder builder;
+  const std::vector<srt_prim>& s = builder.build(*svg, initial_svg_2_screen(*svg, w, h), sr);
   for (size_t i = 0; i < s.size() && i < cap; i++) out[i] = s[i];
   return (long)s.size();
 }

@@ -70,6 +70,14 @@ def load_library() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and
+    # loads them by absolute path; if the system copy (our DT_NEEDED) were loaded first, torch would bring
+    # up a second HSA runtime that sees no GPU.  Importing torch first makes the loader resolve our
+    # libamdhip64.so.7 to the copy already in the process, so tensors, streams and RCCL share our device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # the C ABI itself has no torch dependency
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.srt_last_error.restype = c_char_p
     lib.srt_raster_create.argtypes = [c_int, POINTER(c_void_p)]

@@ -9,7 +9,7 @@
 //
 // Split of work:
 //   host  : element walk, transform stack, ear-clip triangulation (the reference's own
-//           triangulate()), Xiaolin-Wu line decomposition into rasterize_point blocks
+//           triangulate()), Xiaolin-Wu line decomposition into rasterize_point blocks (svg_stream.cpp)
 //   device: rasterize_triangle + inside_triangle + fill_sample + rasterize_point + resolve
 #ifndef SRT_SOFTWARE_RENDERER_HIP_H
 #define SRT_SOFTWARE_RENDERER_HIP_H
@@ -18,14 +18,13 @@
 
 #include "software_renderer.h"  // the reference's header (CMU462::SoftwareRenderer)
 #include "srt_raster.h"
+#include "svg_stream.h"
 
 namespace CMU462 {
 
 class SoftwareRendererHIP : public SoftwareRenderer {
  public:
-  // connect_device=false builds the ordered stream only (used by the fixture generator,
-  // which has no GPU); any draw_svg call then fails loudly.
-  explicit SoftwareRendererHIP(int device = 0, bool connect_device = true);
+  explicit SoftwareRendererHIP(int device = 0);
   ~SoftwareRendererHIP();
 
   void draw_svg(SVG& svg);
@@ -35,22 +34,12 @@ class SoftwareRendererHIP : public SoftwareRenderer {
   // Mirrors SoftwareRendererImp::clear_target (software_renderer.h:93-98).
   void clear_target();
 
-  // Host half of draw_svg: walks the SVG and returns the ordered primitive stream that
-  // draw_svg hands to srt_raster_submit. Exposed so the stream can be captured as a fixture.
-  const std::vector<srt_prim>& build_stream(SVG& svg);
-
-  // Number of <image> elements skipped by the last build_stream (unsupported on this path).
-  size_t skipped_images() const { return skipped_images_; }
+  // Number of <image> elements skipped by the last draw_svg (unsupported on this path).
+  size_t skipped_images() const { return builder_.skipped_images(); }
 
  private:
-  void walk(SVGElement* element);
-  void emit_triangle(float x0, float y0, float x1, float y1, float x2, float y2, const Color& c);
-  void emit_point(double x, double y, const Color& c);
-  void emit_line(float x0, float y0, float x1, float y1, Color c);
-
   srt_raster* ctx_;
-  std::vector<srt_prim> stream_;
-  size_t skipped_images_;
+  SvgStreamBuilder builder_;  // host half of draw_svg
 };
 
 }  // namespace CMU462

@@ -1,0 +1,219 @@
+// See svg_stream.h. Host element walk for the MI355X rasterizer path.
+//
+// Every arithmetic step that decides WHERE a primitive lands (transform stack, float
+// narrowing at the rasterize_* call boundaries, Xiaolin-Wu endpoint/gradient math) follows
+// the reference expression by expression, because the ordered stream must be identical to
+// the sequence of rasterize_triangle / rasterize_point calls SoftwareRendererImp::draw_svg
+// makes (Assignments/DrawSVG/src/software_renderer.cpp:17-52, 94-265, 303-454).
+#include "svg_stream.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+
+#include "triangulation.h"  // the reference's ear-clipper, reused as-is
+
+namespace CMU462 {
+
+namespace {
+
+// Wu helpers, float in / float out (software_renderer.cpp:355-363).
+inline float wu_floor(float v) { return std::floor(v); }
+inline float wu_frac(float v) { return v - std::floor(v); }
+inline float wu_rfrac(float v) { return 1 - wu_frac(v); }
+
+}  // namespace
+
+const std::vector<srt_prim>& SvgStreamBuilder::build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate) {
+  stream_.clear();
+  skipped_images_ = 0;
+  sample_rate_ = sample_rate;
+  transformation = svg_2_screen;
+
+  for (size_t i = 0; i < svg.elements.size(); ++i) walk(svg.elements[i]);
+
+  // Canvas outline: four corners pushed one pixel outwards, then four lines (cpp:31-48).
+  Vector2D a = transform(Vector2D(0, 0));
+  Vector2D b = transform(Vector2D(svg.width, 0));
+  Vector2D c = transform(Vector2D(0, svg.height));
+  Vector2D d = transform(Vector2D(svg.width, svg.height));
+  a.x--; a.y--;
+  b.x++; b.y--;
+  c.x--; c.y++;
+  d.x++; d.y++;
+  emit_line(a.x, a.y, b.x, b.y, Color::Black);
+  emit_line(a.x, a.y, c.x, c.y, Color::Black);
+  emit_line(d.x, d.y, b.x, b.y, Color::Black);
+  emit_line(d.x, d.y, c.x, c.y, Color::Black);
+  return stream_;
+}
+
+void SvgStreamBuilder::walk(SVGElement* e) {
+  // Push: T <- T * M_e. Pop: T <- T * inv(M_e); the pop is NOT an exact undo in floating
+  // point and later siblings see the drifted matrix, exactly as in the reference (cpp:102,133).
+  transformation = transformation * e->transform;
+
+  switch (e->type) {
+    case POINT: {
+      Point& pt = static_cast<Point&>(*e);
+      Vector2D p = transform(pt.position);
+      emit_point(p.x, p.y, pt.style.fillColor);
+    } break;
+
+    case LINE: {
+      Line& ln = static_cast<Line&>(*e);
+      Vector2D p0 = transform(ln.from);
+      Vector2D p1 = transform(ln.to);
+      emit_line(p0.x, p0.y, p1.x, p1.y, ln.style.strokeColor);
+    } break;
+
+    case POLYLINE: {
+      Polyline& pl = static_cast<Polyline&>(*e);
+      Color c = pl.style.strokeColor;
+      if (c.a != 0) {
+        int n = (int)pl.points.size();
+        for (int i = 0; i + 1 < n; i++) {
+          Vector2D p0 = transform(pl.points[i]);
+          Vector2D p1 = transform(pl.points[i + 1]);
+          emit_line(p0.x, p0.y, p1.x, p1.y, c);
+        }
+      }
+    } break;
+
+    case RECT: {
+      Rect& rc = static_cast<Rect&>(*e);
+      // corner coordinates pass through float first (cpp:176-184)
+      float x = rc.position.x, y = rc.position.y;
+      float w = rc.dimension.x, h = rc.dimension.y;
+      Vector2D p0 = transform(Vector2D(x, y));
+      Vector2D p1 = transform(Vector2D(x + w, y));
+      Vector2D p2 = transform(Vector2D(x, y + h));
+      Vector2D p3 = transform(Vector2D(x + w, y + h));
+      Color c = rc.style.fillColor;
+      if (c.a != 0) {
+        emit_triangle(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, c);
+        emit_triangle(p2.x, p2.y, p1.x, p1.y, p3.x, p3.y, c);
+      }
+      c = rc.style.strokeColor;
+      if (c.a != 0) {
+        emit_line(p0.x, p0.y, p1.x, p1.y, c);
+        emit_line(p1.x, p1.y, p3.x, p3.y, c);
+        emit_line(p3.x, p3.y, p2.x, p2.y, c);
+        emit_line(p2.x, p2.y, p0.x, p0.y, c);
+      }
+    } break;
+
+    case POLYGON: {
+      Polygon& pg = static_cast<Polygon&>(*e);
+      Color c = pg.style.fillColor;
+      if (c.a != 0) {
+        std::vector<Vector2D> tris;
+        triangulate(pg, tris);
+        for (size_t i = 0; i + 2 < tris.size(); i += 3) {
+          Vector2D p0 = transform(tris[i]);
+          Vector2D p1 = transform(tris[i + 1]);
+          Vector2D p2 = transform(tris[i + 2]);
+          emit_triangle(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, c);
+        }
+      }
+      c = pg.style.strokeColor;
+      if (c.a != 0) {
+        int n = (int)pg.points.size();
+        for (int i = 0; i < n; i++) {
+          Vector2D p0 = transform(pg.points[i]);
+          Vector2D p1 = transform(pg.points[(i + 1) % n]);
+          emit_line(p0.x, p0.y, p1.x, p1.y, c);
+        }
+      }
+    } break;
+
+    case GROUP: {
+      Group& g = static_cast<Group&>(*e);
+      for (size_t i = 0; i < g.elements.size(); ++i) walk(g.elements[i]);
+    } break;
+
+    case IMAGE:
+      // rasterize_image + Sampler2D are outside this path. No CPU
+      // fallback exists on purpose: say so loudly and skip the element.
+      if (skipped_images_++ == 0)
+        std::fprintf(stderr, "[SvgStreamBuilder] <image> elements are not supported on the HIP path; skipped\n");
+      break;
+
+    case ELLIPSE:  // draw_ellipse is empty in the reference (cpp:243-247)
+    default:
+      break;
+  }
+
+  transformation = transformation * e->transform.inv();
+}
+
+void SvgStreamBuilder::emit_triangle(float x0, float y0, float x1, float y1, float x2, float y2,
+                                        const Color& c) {
+  srt_prim p;
+  std::memset(&p, 0, sizeof p);
+  p.kind = SRT_PRIM_TRIANGLE;
+  p.v.tri[0] = x0; p.v.tri[1] = y0;
+  p.v.tri[2] = x1; p.v.tri[3] = y1;
+  p.v.tri[4] = x2; p.v.tri[5] = y2;
+  p.rgba[0] = c.r; p.rgba[1] = c.g; p.rgba[2] = c.b; p.rgba[3] = c.a;
+  stream_.push_back(p);
+}
+
+void SvgStreamBuilder::emit_point(double x, double y, const Color& c) {
+  srt_prim p;
+  std::memset(&p, 0, sizeof p);
+  p.kind = SRT_PRIM_POINT;
+  p.v.point[0] = x;
+  p.v.point[1] = y;
+  p.rgba[0] = c.r; p.rgba[1] = c.g; p.rgba[2] = c.b; p.rgba[3] = c.a;
+  stream_.push_back(p);
+}
+
+// Xiaolin Wu anti-aliased line -> ordered rasterize_point calls (cpp:365-454). All math in
+// float, as in the reference; the stroke alpha is REPLACED by the Wu coverage, not scaled.
+void SvgStreamBuilder::emit_line(float x0, float y0, float x1, float y1, Color color) {
+  const bool steep = std::abs(x1 - x0) < std::abs(y1 - y0);
+  if (steep) { std::swap(x0, y0); std::swap(x1, y1); }
+  if (x0 > x1) { std::swap(x0, x1); std::swap(y0, y1); }
+
+  const float dx = x1 - x0;
+  const float dy = y1 - y0;
+  const float gradient = (dx == 0.0f) ? 1.0f : dy / dx;
+
+  // (major, minor) -> (x, y) or (y, x)
+  auto plot = [&](float major, float minor, float alpha) {
+    color.a = alpha;
+    if (steep) emit_point(minor, major, color);
+    else       emit_point(major, minor, color);
+  };
+
+  // first endpoint
+  float xend = std::round(x0);
+  float yend = y0 + gradient * (xend - x0);
+  float xgap = wu_rfrac(x0 + 0.5f);
+  const float xpxl1 = xend;
+  const float ypxl1 = wu_floor(yend);
+  plot(xpxl1, ypxl1, wu_rfrac(yend) * xgap);
+  plot(xpxl1, ypxl1 + 1, wu_frac(yend) * xgap);
+  float intery = yend + gradient;
+
+  // second endpoint
+  xend = std::round(x1);
+  yend = y1 + gradient * (xend - x1);
+  xgap = wu_frac(x1 + 0.5f);
+  const float xpxl2 = xend;
+  const float ypxl2 = wu_floor(yend);
+  plot(xpxl2, ypxl2, wu_rfrac(yend) * xgap);
+  plot(xpxl2, ypxl2 + 1, wu_frac(yend) * xgap);
+
+  // interior; note the reference's upper bound subtracts sample_rate (cpp:434,445)
+  const float last = xpxl2 - 1 * sample_rate_;
+  for (float x = xpxl1 + 1; x <= last; ++x) {
+    plot(x, wu_floor(intery), wu_rfrac(intery));
+    plot(x, wu_floor(intery) + 1, wu_frac(intery));
+    intery += gradient;
+  }
+}
+
+}  // namespace CMU462

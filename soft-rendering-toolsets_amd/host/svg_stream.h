@@ -1,0 +1,44 @@
+// SvgStreamBuilder — the HOST half of SoftwareRendererImp::draw_svg: walks an SVG and emits the ordered
+// primitive stream (include/srt_raster.h: srt_prim) that the device rasterizes.  No device dependency:
+// this file needs only the reference's headers and srt_raster.h's record layout.
+//
+// Compiled INSIDE the reference tree (Assignments/DrawSVG/src); see INTEGRATION.md.
+#ifndef SRT_SVG_STREAM_H
+#define SRT_SVG_STREAM_H
+
+#include <vector>
+
+#include "svg_renderer.h"  // the reference's SVGRenderer (transform stack helpers)
+#include "srt_raster.h"
+
+namespace CMU462 {
+
+class SvgStreamBuilder : public SVGRenderer {
+ public:
+  SvgStreamBuilder() : sample_rate_(1), skipped_images_(0) {}
+
+  // SVGRenderer interface: same as build().
+  void draw_svg(SVG& svg) { build(svg, transformation, sample_rate_); }
+
+  // Walk `svg` with top-level transform svg_2_screen.  sample_rate only enters through the reference's
+  // Xiaolin-Wu loop bound (software_renderer.cpp:434,445).
+  const std::vector<srt_prim>& build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate);
+
+  const std::vector<srt_prim>& stream() const { return stream_; }
+  // Number of <image> elements skipped by the last build (unsupported on this path).
+  size_t skipped_images() const { return skipped_images_; }
+
+ private:
+  void walk(SVGElement* element);
+  void emit_triangle(float x0, float y0, float x1, float y1, float x2, float y2, const Color& c);
+  void emit_point(double x, double y, const Color& c);
+  void emit_line(float x0, float y0, float x1, float y1, Color c);
+
+  size_t sample_rate_;
+  std::vector<srt_prim> stream_;
+  size_t skipped_images_;
+};
+
+}  // namespace CMU462
+
+#endif
