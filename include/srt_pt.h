@@ -96,8 +96,8 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
  * written.  Synchronous. */
 int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_t samples, float* rgb_out);
 /* Device form: d_tiles_out is DEVICE memory of tiles_per_rank * floats_per_tile floats, tile-major
- * (local tile k = global tile rank + k * world); enqueued on `stream` (hipStream_t, NULL = context
- * stream), not synchronized.  This is the buffer the RCCL gather moves. */
+ * (local tile k = global tile rank + k * world); enqueued on `stream` (hipStream_t; NULL = the HIP
+ * default stream, which is also PyTorch's default), not synchronized.  This is the buffer the RCCL gather moves. */
 int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples,
                                float* d_tiles_out);
 /* d_gathered: DEVICE, world * tiles_per_rank * floats_per_tile floats as gathered on the root (rank-major).

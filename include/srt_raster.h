@@ -92,7 +92,7 @@ int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out);
 
 /* Same as srt_raster_resolve but leaves the RGBA8 image in device memory (pointer valid until the next
  * set_target/destroy) and does not synchronize the stream; used by the resident-input benchmark.
- * `stream` is a hipStream_t (NULL = the context's own stream). */
+ * `stream` is the hipStream_t to enqueue on (NULL = the HIP default stream, which is also PyTorch's default). */
 int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgba8_out);
 
 /* Optional: read back the supersample buffer (float RGBA, (width*sr)*(height*sr)*4 floats, row-major)

@@ -813,7 +813,7 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
   int st = need_ready(pt, "srt_pt_render_epoch_device");
   if (st != SRT_OK) return st;
   if (!d_tiles_out) return srt::fail(SRT_ERR_INVALID, "srt_pt_render_epoch_device: output is NULL");
-  hipStream_t s = stream ? (hipStream_t)stream : pt->stream;
+  hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream; NULL is the HIP default stream
   const TileMap& T = pt->tiles;
   const uint64_t lanes = (uint64_t)T.local_tiles * T.tile_w * T.tile_h;
   if (lanes) {
@@ -829,7 +829,7 @@ int srt_pt_untile_device(srt_pt* pt, void* stream, const float* d_gathered, floa
   int st = need_ready(pt, "srt_pt_untile_device");
   if (st != SRT_OK) return st;
   if (!d_gathered || !d_image) return srt::fail(SRT_ERR_INVALID, "srt_pt_untile_device: NULL buffer");
-  hipStream_t s = stream ? (hipStream_t)stream : pt->stream;
+  hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream; NULL is the HIP default stream
   const uint32_t n = pt->w * pt->h;
   pt_untile_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(pt->tiles, pt->w, pt->h, pt->tiles_per_rank, d_gathered, d_image);
   SRT_HIP(hipGetLastError());
@@ -841,7 +841,7 @@ int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, con
   int st = need_device(pt, "srt_pt_accumulate_device");
   if (st != SRT_OK) return st;
   if (!d_accumulator || !d_epoch || !accumulator_samples) return srt::fail(SRT_ERR_INVALID, "srt_pt_accumulate_device: bad argument");
-  hipStream_t s = stream ? (hipStream_t)stream : pt->stream;
+  hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream; NULL is the HIP default stream
   pt_accumulate_kernel<<<dim3((unsigned)((nfloats + 255) / 256)), dim3(256), 0, s>>>(d_accumulator, d_epoch, nfloats,
                                                                                  1.0f / accumulator_samples);
   SRT_HIP(hipGetLastError());
@@ -861,7 +861,7 @@ int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_
     SRT_HIP(hipMalloc(&pt->d_tile_buf, need * sizeof(float)));
     pt->tile_buf_floats = need;
   }
-  st = srt_pt_render_epoch_device(pt, nullptr, seed, sample_base, samples, pt->d_tile_buf);
+  st = srt_pt_render_epoch_device(pt, (void*)pt->stream, seed, sample_base, samples, pt->d_tile_buf);
   if (st != SRT_OK) return st;
   std::vector<float> host(per_tile * T.local_tiles);
   if (!host.empty()) SRT_HIP(hipMemcpyAsync(host.data(), pt->d_tile_buf, host.size() * sizeof(float), hipMemcpyDeviceToHost, pt->stream));

@@ -428,7 +428,7 @@ int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgb
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve_device: NULL context");
   if (!r->have_target) return srt::fail(SRT_ERR_STATE, "resolve before srt_raster_set_target");
   SRT_HIP(hipSetDevice(r->device));
-  hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+  hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream; NULL is the HIP default stream
   if (r->dirty) {
     int st = upload_stream(r);
     if (st != SRT_OK) return st;
@@ -442,7 +442,8 @@ int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgb
 
 int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out) {
   if (!rgba8_out) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve: output buffer is NULL");
-  int st = srt_raster_resolve_device(r, nullptr, nullptr);
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve: NULL context");
+  int st = srt_raster_resolve_device(r, (void*)r->stream, nullptr);
   if (st != SRT_OK) return st;
   SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));
   SRT_HIP(hipStreamSynchronize(r->stream));

@@ -132,10 +132,16 @@ def test_epoch_image_and_tiling(srt):
     gathered = torch.cat(bufs)
     image = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
     pt.untile_device(torch.cuda.current_stream().cuda_stream, gathered.data_ptr(), image.data_ptr())
-    acc = torch.zeros_like(image)
-    pt.accumulate_device(torch.cuda.current_stream().cuda_stream, acc.data_ptr(), image.data_ptr(), image.numel(), 1)
     torch.cuda.synchronize()
-    assert bits_equal(acc.cpu().numpy().reshape(h, w, 3), want)
+    assert bits_equal(image.cpu().numpy().reshape(h, w, 3), want), "gather + untile differs from the single-rank image"
+    acc = torch.full_like(image, 0.25)
+    for k in (1, 2, 3):
+        pt.accumulate_device(torch.cuda.current_stream().cuda_stream, acc.data_ptr(), image.data_ptr(), image.numel(), k)
+    torch.cuda.synchronize()
+    ref_acc = np.full((h, w, 3), 0.25, np.float32)
+    for k in (1, 2, 3):
+        H.oracle_accumulate(ref_acc, want, k)
+    assert bits_equal(acc.cpu().numpy().reshape(h, w, 3), ref_acc)
     pt.close()
 
 
