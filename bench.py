@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native hot paths.
+
+Metric (BASELINE.json): Mrays/s on the Cornell box, 1024x1024, 2048 spp, image-tiled over N GPUs;
+plus Mfrags/s of the DrawSVG triangle fill (single GPU) as a second object on the same JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One STEP = one epoch (Pathtracer::do_trace) of --spp-per-step (default 64) samples per pixel over the whole
+1024x1024 image: 67.1 M camera samples, ~0.5 G rays.  32 steps are the full 2048-spp render of
+BASELINE configs[3]; throughput does not depend on K.  Each rank renders its tiles (32x32, round-robin),
+rank 0 gathers the tile radiance with one RCCL gather per step, un-tiles and folds the epoch into the
+running mean (Pathtracer::accumulate).  A ray is one scene.hit call; rays are counted
+on the device by the production kernel.  Inputs (scene, camera) are resident in HBM before the timed
+region; the timed region is bracketed by barrier + synchronize and the max over ranks is reported.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def bytes_per_ray(counters):
+    """Algorithmic bytes per ray, SURVEY.md §8(d): 32 B per BVH node visited (TLAS + BLAS), 128 B per
+    object entered (trans + itrans), 36 B per triangle tested, 4 B per sphere tested, 36 B hit normals."""
+    r = float(counters["rays"])
+    return (32.0 * (counters["tlas_nodes"] + counters["blas_nodes"]) + 128.0 * counters["objects_entered"]
+            + 36.0 * counters["tri_tests"] + 4.0 * counters["sphere_tests"]) / r + 36.0
+
+
+def cpu_cores():
+    """Host threads to use: the cgroup CPU quota when there is one (a 1-GPU box gets a 16-CPU share of a
+    much larger host), else the affinity mask."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("SRT_BENCH_CPU_THREADS", "16")))
+
+
+def pt_cpu_baseline(scene, w, h, depth, seed, budget_s=15.0):
+    """The oracle (validated CPU restatement of the reference) on the host cores, same scene / size /
+    seed, reduced spp: rows are split over `cores` threads (ctypes releases the GIL)."""
+    import _harness as H
+
+    cores = cpu_cores()
+    o = H.OraclePT(scene, w, h, depth, True, math_mode=1)
+    img = np.zeros((h, w, 3), np.float32)
+
+    def run(spp, rows):
+        cnts = [np.zeros(8, np.uint64) for _ in range(cores)]
+        bounds = np.linspace(0, rows, cores + 1).astype(int)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda k: o.epoch(seed, 0, spp, int(bounds[k]), int(bounds[k + 1]), img, cnts[k]), range(cores)))
+        dt = time.perf_counter() - t0
+        return dt, int(sum(int(c[0]) for c in cnts))
+
+    dt, rays = run(1, max(cores, h // 8))           # probe: 1/8 of the rows at 1 spp
+    per_spp_full = dt * 8.0
+    spp = int(max(1, min(64, budget_s / max(per_spp_full, 1e-3))))
+    dt, rays = run(spp, h)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/pt_oracle.c, same scene/seed, {w}x{h} at {spp} spp ({rays / 1e6:.1f} M rays in {dt:.1f} s), "
+                      f"{w * h * spp / dt / 1e6:.2f} M camera samples/s"}
+
+
+def raster_bench(device, frames=30, warmup=3):
+    """BASELINE configs[1]: basic/test3.svg (1963 triangles + Wu-line points), 1024x1024, supersample 4.
+    A frame = clear + ordered fill + resolve with the primitive stream resident in HBM."""
+    import torch
+
+    import _harness as H
+    import srt_amd
+
+    g = np.load(os.path.join(H.GOLDEN, "raster_cfg2_test3_1024_ss4.npz"))
+    w, h, sr = (int(x) for x in g["meta"])
+    ren = srt_amd.SoftwareRenderer(device)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(sr)
+    ren.clear_target()
+    ren.submit(g["prims"])
+    out = ren.resolve()                      # uploads the stream, checks the result
+    ok = bool(np.array_equal(out, g["rgba"]))
+    st = ren.stats()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        ren.resolve_device(stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(frames):
+        ren.resolve_device(stream)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / frames
+    alg_bytes = 40.0 * st.bin_entries + 4.0 * w * h          # SURVEY.md §8(d) rasterizer formula (fused resolve)
+    t = time.perf_counter()
+    o_rgba, _, counts = H.oracle_raster_frame(g["prims"], w, h, sr)
+    cpu_s = time.perf_counter() - t
+    ren.close()
+    return {
+        "metric": "Mfrags/s triangle fill", "value": st.fragments / (ms * 1e-3) / 1e6, "unit": "Mfrags/s",
+        "ms_per_frame": ms, "wall_ms_per_frame": wall * 1e3 / frames, "frames": frames,
+        "config": {"workload": "DrawSVG basic/test3.svg 1024x1024 supersample=4 (BASELINE configs[1])",
+                   "triangles": int((g["prims"]["kind"] == 1).sum()), "points": int((g["prims"]["kind"] == 2).sum()),
+                   "fragments": int(st.fragments), "sample_tests": int(st.sample_tests), "bin_entries": int(st.bin_entries)},
+        "sample_tests_per_s": st.sample_tests / (ms * 1e-3),
+        "bit_exact_vs_reference_golden": ok, "dtype": "f64 edge functions / f32 blend",
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "tile kernel is LDS/VALU bound: the 256 MiB supersample buffer never leaves the CUs"},
+        "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1, "kind": "port",
+                         "sample": f"oracle/raster_oracle.c, one full frame of the same stream in {cpu_s * 1e3:.0f} ms"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_lambertian"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-raster", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import srt_amd
+    from soft_rendering_toolsets_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = args.size
+    spp = args.spp_per_step
+    scene = scenes.cornell_box(args.scene)
+    pt = srt_amd.Pathtracer(local_rank)
+    pt.set_params(W, H, spp * args.steps, args.depth, True)
+    pt.build_scene(scene)
+    pt.set_camera(scene["camera"])
+    pt.set_tiling(32, 32, rank, world)
+    local_tiles, per_rank, fpt = pt.tile_info()
+
+    dev = torch.device("cuda", local_rank)
+    tiles = torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(world * per_rank * fpt, dtype=torch.float32, device=dev) if rank == 0 else None
+    gather_list = list(gathered.view(world, -1).unbind(0)) if (rank == 0 and world > 1) else None
+    image = torch.zeros(W * H * 3, dtype=torch.float32, device=dev) if rank == 0 else None
+    acc = torch.zeros(W * H * 3, dtype=torch.float32, device=dev) if rank == 0 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    kernel_events = []
+
+    def step(i, timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        pt.render_epoch_device(stream, args.seed, i * spp, spp, tiles.data_ptr())
+        if timed:
+            e1.record()
+            kernel_events.append((e0, e1))
+        if world > 1:
+            dist.gather(tiles, gather_list, dst=0)     # RCCL over xGMI: tile radiance -> rank 0
+        if rank == 0:
+            src = gathered if world > 1 else tiles
+            pt.untile_device(stream, src.data_ptr(), image.data_ptr())
+            pt.accumulate_device(stream, acc.data_ptr(), image.data_ptr(), image.numel(), i + 1)
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    pt.ray_count(reset=True)
+    if rank == 0:
+        acc.zero_()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    rays, cams = pt.ray_count()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max = float(t[0]), float(t[1])
+        c = torch.tensor([rays, cams], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_rays, total_cams = int(c[0]), int(c[1])
+    else:
+        kernel_ms_max, total_rays, total_cams = kernel_ms, rays, cams
+
+    if rank == 0:
+        # traversal averages of this workload from an instrumented launch (outside the timed region)
+        rng = np.random.default_rng(1)
+        n = 1 << 16
+        xs, ys = rng.integers(0, W, n).astype(np.uint32), rng.integers(0, H, n).astype(np.uint32)
+        ss = rng.integers(0, spp * args.steps, n).astype(np.uint32)
+        pt.trace_samples(args.seed, xs, ys, ss)
+        cnt = pt.counters()
+        bpr = bytes_per_ray(cnt)
+        rays_per_launch_rank0 = rays / args.steps
+        achieved = bpr * rays_per_launch_rank0 / (kernel_ms * 1e-3) / 1e9
+        mean_radiance = float(acc.mean().item())
+        out = {
+            "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"Scotty3D Pathtracer: Cornell box ({args.scene}: area light + MIS"
+                            f"{', mirror + glass spheres' if args.scene == 'cbox' else ''}), {W}x{H}, {spp} spp per step "
+                            f"({args.steps} steps = {spp * args.steps} spp; 32 steps = BASELINE configs[3] 2048 spp), depth {args.depth}, BVH on",
+                "tiles": "32x32 round-robin over ranks", "collective": "one RCCL gather of tile radiance per step" if world > 1 else "none (1 GPU)",
+                "seed": args.seed,
+            },
+            "camera_samples_per_s": total_cams / elapsed, "rays": total_rays, "camera_samples": total_cams,
+            "rays_per_camera_sample": total_rays / max(1, total_cams),
+            "rays_counted": "every scene.hit the reference performs (no ray is elided)",
+            "mean_radiance": mean_radiance,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "pt_epoch_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                "algorithmic_bytes_per_ray": bpr,
+                "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
+                "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d)",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed)
+        if not args.no_raster and world == 1:
+            out["raster"] = raster_bench(local_rank)
+        print(json.dumps(out), flush=True)
+    pt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

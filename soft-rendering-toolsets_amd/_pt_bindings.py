@@ -196,6 +196,12 @@ class Pathtracer:
     def accumulate_device(self, stream: int, d_acc: int, d_epoch: int, nfloats: int, k: int) -> None:
         self._check(self._lib, self._lib.srt_pt_accumulate_device(self._ctx, c_void_p(stream), c_void_p(d_acc), c_void_p(d_epoch), nfloats, k))
 
+    def ray_count(self, reset: bool = False):
+        """(rays, camera_samples) traced by render_epoch* since the last reset (synchronizes the device)."""
+        r, c = c_uint64(), c_uint64()
+        self._check(self._lib, self._lib.srt_pt_ray_count(self._ctx, ctypes.byref(r), ctypes.byref(c), int(reset)))
+        return r.value, c.value
+
     def trace_samples(self, seed: int, xs, ys, ss):
         xs, ys, ss = (np.ascontiguousarray(a, np.uint32) for a in (xs, ys, ss))
         rgb = np.zeros((len(xs), 3), np.float32)

@@ -14,6 +14,7 @@
 // bounce back to the first instead of carrying a running throughput.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -210,7 +211,7 @@ SRT_DEV void object_hit(const DScene& S, uint32_t slot, const Ray& wray, Hit& ac
 // scene.hit(ray): BVH<Object>::hit or List<Object>::hit; the scene Object itself has no transform.
 template <bool COUNT>
 SRT_DEV Hit scene_hit(const DScene& S, const Ray& ray, Counters& cnt) {
-  if (COUNT) cnt.v[C_RAYS]++;
+  cnt.v[C_RAYS]++;  // always: the Mrays/s metric counts scene.hit calls
   if (S.use_bvh) {
     Hit none; none.hit = false; none.dist = 0.0f; none.obj = 0; none.tri = 0;
     if (S.tlas_nodes == 0) return none;
@@ -491,21 +492,25 @@ __global__ __launch_bounds__(64) void pt_epoch_kernel(DScene S, TileMap T, uint6
   const uint32_t tile = T.rank + local_tile * T.world;
   const uint32_t x = (tile % T.tiles_x) * T.tile_w + lx, y = (tile / T.tiles_x) * T.tile_h + ly;
   float* out = tiles_out + ((size_t)local_tile * px_per_tile + (size_t)ly * T.tile_w + lx) * 3;
-  if (x >= S.w || y >= S.h) { out[0] = out[1] = out[2] = 0.0f; return; }
   Counters cnt;
   cnt.v[C_RAYS] = 0;
+  const bool inside = x < S.w && y < S.h;
+  if (!inside) samples = 0;  // padding lanes of edge tiles: no samples, zero output, still join the wave reduction
   Rng rng;
   Spec acc = spec(0, 0, 0);
   uint32_t sampled = 0;
   for (uint32_t s = 0; s < samples; s++) {
     rng.key(seed, y * S.w + x, sample_base + s);
     const Spec p = path_sample<false>(S, x, y, rng, cnt);
-    // rays are counted separately (C_RAYS is compiled out with COUNT=false); see pt_count_kernel
     if (valid(p)) { acc = acc + p; sampled++; }
   }
   if (sampled > 0) acc = acc * (1.0f / sampled);
   out[0] = acc.r; out[1] = acc.g; out[2] = acc.b;
-  (void)ray_counter;
+  if (ray_counter) {  // one atomic per wavefront (every lane of the wave reaches this point)
+    unsigned long long r = cnt.v[C_RAYS];
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(ray_counter, r);
+  }
 }
 
 // Explicit (x, y, sample) triples; instrumented when COUNT.
@@ -599,9 +604,9 @@ struct srt_pt {
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
-  unsigned long long* d_totals = nullptr;
+  unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
   unsigned long long last_counters[C_COUNT] = {0};
-  uint64_t rays = 0, camera_samples = 0;
+  uint64_t camera_samples = 0;
 };
 
 namespace {
@@ -652,9 +657,6 @@ void update_tiling(srt_pt* pt) {
   T.local_tiles = (ntiles > T.rank) ? (ntiles - T.rank + T.world - 1) / T.world : 0;
 }
 
-// Average rays per camera sample is scene dependent; the exact count comes from an instrumented launch.
-int count_rays_of_epoch(srt_pt*, uint32_t) { return SRT_OK; }
-
 }  // namespace
 
 extern "C" {
@@ -674,7 +676,8 @@ int srt_pt_create(int device, srt_pt** out) {
     }
     if (device >= count) { delete pt; return srt::fail(SRT_ERR_INVALID, "device %d out of range [0,%d)", device, count); }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pt->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&pt->d_totals, C_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&pt->d_totals, (C_COUNT + 1) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(pt->d_totals, 0, (C_COUNT + 1) * sizeof(unsigned long long)) != hipSuccess) {
       delete pt;
       return srt::fail(SRT_ERR_HIP, "HIP context setup failed on device %d", device);
     }
@@ -818,10 +821,18 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
   const uint64_t lanes = (uint64_t)T.local_tiles * T.tile_w * T.tile_h;
   if (lanes) {
     const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
-    pt_epoch_kernel<<<dim3(blocks), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base, samples, d_tiles_out, nullptr);
+    pt_epoch_kernel<<<dim3(blocks), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base, samples, d_tiles_out,
+                                                      pt->d_totals + C_COUNT);
     SRT_HIP(hipGetLastError());
+    // camera samples of this epoch: pixels of this rank's tiles that lie inside the image
+    uint64_t px = 0;
+    for (uint32_t k = 0; k < T.local_tiles; k++) {
+      const uint32_t tile = T.rank + k * T.world;
+      const uint32_t x0 = (tile % T.tiles_x) * T.tile_w, y0 = (tile / T.tiles_x) * T.tile_h;
+      px += (uint64_t)std::min(T.tile_w, pt->w - x0) * std::min(T.tile_h, pt->h - y0);
+    }
+    pt->camera_samples += px * samples;
   }
-  (void)count_rays_of_epoch;
   return SRT_OK;
 }
 
@@ -880,10 +891,17 @@ int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_
 }
 
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset) {
-  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_ray_count: NULL context");
-  if (rays) *rays = pt->rays;
+  int st = need_device(pt, "srt_pt_ray_count");
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipDeviceSynchronize());  // epochs may be in flight on any stream
+  unsigned long long r = 0;
+  SRT_HIP(hipMemcpy(&r, pt->d_totals + C_COUNT, sizeof r, hipMemcpyDeviceToHost));
+  if (rays) *rays = r;
   if (camera_samples) *camera_samples = pt->camera_samples;
-  if (reset) pt->rays = pt->camera_samples = 0;
+  if (reset) {
+    SRT_HIP(hipMemset(pt->d_totals + C_COUNT, 0, sizeof r));
+    pt->camera_samples = 0;
+  }
   return SRT_OK;
 }
 
