@@ -107,6 +107,11 @@ int srt_pt_untile_device(srt_pt* pt, void* stream, const float* d_gathered, floa
 int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, const float* d_epoch, size_t nfloats,
                              uint32_t accumulator_samples);
 
+/* Kernel selection for render_epoch*: 0 = automatic (default), 1 = general per-lane kernel (any scene),
+ * 2 = wave-uniform persistent kernel (scenes with at most 16 objects; fails otherwise).  Both produce
+ * bit-identical images; the switch exists for A/B tests and profiling. */
+int srt_pt_set_kernel(srt_pt* pt, int mode);
+
 /* Rays (scene.hit calls) and camera samples traced by this context since the last reset. */
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);
 

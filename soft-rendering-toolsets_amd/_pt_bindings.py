@@ -34,6 +34,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_render_epoch_device.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]
     lib.srt_pt_untile_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_accumulate_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint32]
+    lib.srt_pt_set_kernel.argtypes = [c_void_p, c_int]
     lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -195,6 +196,10 @@ class Pathtracer:
 
     def accumulate_device(self, stream: int, d_acc: int, d_epoch: int, nfloats: int, k: int) -> None:
         self._check(self._lib, self._lib.srt_pt_accumulate_device(self._ctx, c_void_p(stream), c_void_p(d_acc), c_void_p(d_epoch), nfloats, k))
+
+    def set_kernel(self, mode: int) -> None:
+        """0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel."""
+        self._check(self._lib, self._lib.srt_pt_set_kernel(self._ctx, int(mode)))
 
     def ray_count(self, reset: bool = False):
         """(rays, camera_samples) traced by render_epoch* since the last reset (synchronizes the device)."""
