@@ -162,6 +162,7 @@ struct srt_pt {
   // device copies
   Node* d_nodes = nullptr; Tri* d_tris = nullptr; TriNrm* d_nrm = nullptr; Object* d_objects = nullptr;
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
+  WaveInterior* d_wave = nullptr;
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
@@ -207,6 +208,7 @@ DScene device_scene(const srt_pt* pt) {
   DScene S;
   S.nodes = pt->d_nodes; S.tris = pt->d_tris; S.tri_nrm = pt->d_nrm; S.objects = pt->d_objects;
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
+  S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size();
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.cam = pt->cam; S.w = pt->w; S.h = pt->h; S.max_depth = pt->max_depth;
@@ -239,7 +241,7 @@ int ensure(T** buf, size_t* have, size_t need) {
 bool wave_kernel_applies(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   if (pt->kernel_mode == 1) return false;
-  return F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tlas_nodes <= 2 * kWaveMaxObjects;
+  return F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
 }
 
 // One epoch with the wave-uniform persistent kernel: launches of <= 64 samples per pixel, each followed by the
@@ -248,7 +250,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
-  const size_t lds = ((size_t)F.tlas_nodes * 2 + (size_t)4 * F.objects.size() * 3 * 64 * 2 / 4) * sizeof(float4);
+  const size_t lds = (size_t)4 * (F.use_bvh ? F.wave_tlas.size() : 0) * 9 * 64 * sizeof(float);  // 4 waves x Q x 3 rays x 3 fields
   if (pt->wave_blocks == 0 || pt->wave_lds != lds) {
     int per_cu = 0, cus = 0;
     SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -321,7 +323,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipSetDevice(pt->device);
     (void)hipStreamSynchronize(pt->stream);
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
-    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats);
+    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
     (void)hipStreamDestroy(pt->stream);
@@ -398,7 +400,8 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
     int st;
     if ((st = upload(&pt->d_nodes, F.nodes)) || (st = upload(&pt->d_tris, F.tris)) || (st = upload(&pt->d_nrm, F.tri_nrm)) ||
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
-        (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)))
+        (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
+        (st = upload(&pt->d_wave, F.wave_tlas)))
       return st;
   }
   pt->committed = true;

@@ -298,6 +298,25 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
   if (use_bvh) append_nodes(B.tlas, &F);
   F.tlas_nodes = (uint32_t)F.nodes.size();
   F.max_tlas_depth = use_bvh ? interior_depth(B.tlas) : 0;
+  if (use_bvh) {  // interior-node sweep order for the wave-uniform kernel
+    const std::vector<HostNode>& N = B.tlas.nodes;
+    std::vector<int32_t> rank(N.size(), -1);
+    int32_t q = 0;
+    for (size_t n = 0; n < N.size(); n++)
+      if (N[n].l != N[n].r) rank[n] = q++;
+    for (size_t n = 0; n < N.size(); n++) {
+      if (N[n].l == N[n].r) continue;
+      WaveInterior wi;
+      const HostNode& a = N[N[n].l];
+      const HostNode& b = N[N[n].r];
+      for (int i = 0; i < 3; i++) { wi.boxl[i] = a.mn[i]; wi.boxl[3 + i] = a.mx[i]; wi.boxr[i] = b.mn[i]; wi.boxr[3 + i] = b.mx[i]; }
+      wi.l_ref = (a.l != a.r) ? rank[N[n].l] : ~(int32_t)a.start;
+      wi.r_ref = (b.l != b.r) ? rank[N[n].r] : ~(int32_t)b.start;
+      wi.l_cnt = a.size;
+      wi.r_cnt = b.size;
+      F.wave_tlas.push_back(wi);
+    }
+  }
   auto append_triangles = [&](const MeshInput& m, const std::vector<uint32_t>* order) {
     const uint32_t ntri = (uint32_t)m.idx.size() / 3;
     for (uint32_t k = 0; k < ntri; k++) {

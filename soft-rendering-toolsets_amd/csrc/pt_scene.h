@@ -71,6 +71,16 @@ struct Material {
   float ior;
 };
 
+// Top-level tree in the form the wave-uniform kernel sweeps: one record per INTERIOR node of the BVH<Object>,
+// in node-index order (parents before children).  A child is either another interior node (ref = its rank in
+// this array) or a leaf (ref = ~first object slot, cnt = number of objects in the leaf, 0 or 1).
+struct WaveInterior {
+  float boxl[6], boxr[6];   // mn.xyz, mx.xyz of the left / right child
+  int32_t l_ref, r_ref;
+  uint32_t l_cnt, r_cnt;
+};
+static_assert(sizeof(WaveInterior) == 64, "wave interior layout");
+
 struct Camera {
   Mat4 iview;
   float vert_fov, aspect_ratio;
@@ -89,6 +99,7 @@ struct FlatScene {
   uint32_t light_tri_first = 0;
   std::vector<Material> materials;
   uint32_t max_tlas_depth = 0, max_blas_depth = 0;  // interior-node nesting (stack frames needed)
+  std::vector<WaveInterior> wave_tlas;              // empty when the root is a leaf (or in list mode)
 };
 
 // Input side (what the C ABI collects between scene_begin and scene_commit).

@@ -22,6 +22,8 @@ struct DScene {
   const Light* lights;
   const LightTri* light_tris;
   const Material* materials;
+  const WaveInterior* wave_tlas;   // interior nodes of the top-level tree in sweep order (pt_wave.h)
+  uint32_t wave_q;
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
   uint32_t w, h, max_depth;

@@ -8,14 +8,20 @@
 // of the same heavy leaf code (ray -> object space, triangle / sphere tests, hit -> world space).
 // Here that work is done WAVE-UNIFORMLY instead:
 //
-//   phase 1  for every object k (uniform loop; the object's matrices and triangles arrive through the
-//            scalar unit, no per-lane scene loads): all 64 lanes transform their up-to-3 rays into object
-//            space — the three rays of a bounce share their origin, so the origin is transformed once —
-//            run Sphere::hit / the ordered Triangle::hit fold, and park (hit, world distance, triangle) in
-//            a per-lane LDS table.  Only meshes with a real BVH<Triangle> fall back to a per-lane walk.
-//   phase 2  each lane replays find_closest_hit over the small top-level tree (nodes staged in LDS): the
-//            box tests and the visit rule are the reference's, a leaf visit is a table lookup.  Objects the
-//            reference would not have visited are never looked up, so the result is identical by construction.
+//   top-down sweep   over the interior nodes of the top-level tree in index order (parents first, a uniform
+//            loop; the two child boxes arrive through the scalar unit): every lane runs BBox::hit for both
+//            children of node q with the `times` its parent handed down, decides nearer / farther child and
+//            hands (cur_close_t | cur_far_t) down to interior children through a per-lane LDS slot.
+//   bottom-up sweep  over the same nodes in reverse: a leaf child is evaluated on the spot — all 64 lanes
+//            transform their up-to-3 rays into the object's space (the three rays of a bounce share their
+//            origin, so it is transformed once; matrices and triangles are scalar loads), run Sphere::hit or
+//            the ordered Triangle::hit fold and compute the world distance Trace::transform recomputes —
+//            an interior child's result is read back from its LDS slot; then the reference's visit rule
+//            `cur_far_t.x < ret.distance || (!ret.hit && hitboth)` and Trace::min combine the two.
+//   find_closest_hit is a pure function of (node, times), so evaluating every node — including subtrees
+//   the recursion would have skipped, whose results are then simply not selected — gives the identical
+//   answer with no per-lane control flow at all.  Only meshes with a real BVH<Triangle> (more than one
+//   leaf) fall back to a per-lane walk inside the uniform object loop.
 //
 // Lanes run bounce cycles in lockstep: shade -> {BSDF-sampled direct ray, MIS direct ray, indirect ray} in
 // one batch -> shade ...  A lane whose path ends pulls the next (pixel, sample) unit from a global queue
@@ -69,17 +75,107 @@ SRT_DEV uint32_t tile_slot(const TileMap& T, uint32_t p) {
   return local_tile * px_per_tile + ly * T.tile_w + lx;
 }
 
+// Mat4 * Vec3 for wave-uniform matrices: x / 1.0f == x bit for bit, so the perspective divide is skipped
+// when w == 1 in every lane (always the case for affine matrices and finite points).
+SRT_DEV V3 mat_point_uniform(const Mat4& m, V3 v) {
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) o[j] = ((m.c[0][j] * v.x + m.c[1][j] * v.y) + m.c[2][j] * v.z) + m.c[3][j] * 1.0f;
+  if (__ballot(o[3] != 1.0f) == 0ull) return v3(o[0], o[1], o[2]);
+  return v3(o[0] / o[3], o[1] / o[3], o[2] / o[3]);
+}
+
+// BBox::hit with the reciprocal direction hoisted (the reference recomputes the same 1/dir per box).
+SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, float& ty) {
+  const bool sx = inv.x < 0, sy = inv.y < 0, sz = inv.z < 0;
+  float tmin = ((sx ? bx[3] : bx[0]) - o.x) * inv.x;
+  float tmax = ((sx ? bx[0] : bx[3]) - o.x) * inv.x;
+  const float tymin = ((sy ? bx[4] : bx[1]) - o.y) * inv.y;
+  const float tymax = ((sy ? bx[1] : bx[4]) - o.y) * inv.y;
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  const float tzmin = ((sz ? bx[5] : bx[2]) - o.z) * inv.z;
+  const float tzmax = ((sz ? bx[2] : bx[5]) - o.z) * inv.z;
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  if (tmin >= tx && tmin <= ty) tx = tmin;
+  if (tmax >= tx && tmax <= ty) ty = tmax;
+  return true;
+}
+
+// Object::hit of object slot k for the three rays of a batch (shared origin), wave-uniformly: hit flag, the
+// world distance Trace::transform recomputes, and the winning triangle (global index).
+SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
+                          Counters& cnt, bool* hit, float* dist, uint32_t* tri) {
+  const Object& o = S.objects[k];
+  const bool xf = o.has_trans != 0;
+  V3 oorg = org;
+  if (xf) oorg = mat_point_uniform(o.itrans, org);
+  V3 pos[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    Ray ray;
+    ray.o = oorg; ray.d = d[r]; ray.b0 = rb0[r]; ray.b1 = rb1[r];
+    if (xf) {                                         // Ray::transform with the shared origin
+      ray.d = mat_rotate(o.itrans, d[r]);
+      const float dn = norm(ray.d);
+      ray.b0 *= dn; ray.b1 *= dn;
+      ray.d = ray.d / dn;
+    }
+    tri[r] = 0;
+    if (o.kind == OBJ_SPHERE) {
+      const SphHit sh = sphere_hit(o.radius, ray);
+      hit[r] = sh.hit;
+      pos[r] = ray_at(ray, sh.t);
+      dist[r] = fabsf(norm(pos[r] - ray.o));
+    } else if (o.use_bvh && o.nnodes > 1) {           // a real BVH<Triangle>: per-lane walk
+      const Hit mh = mesh_hit<false>(S, o, ray, cnt);
+      hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
+      pos[r] = v3(0, 0, 0);
+      if (mh.hit && xf) { const TriHit th = tri_hit(S.tris[mh.tri], ray); pos[r] = ray_at(ray, th.t); }
+    } else {                                          // one leaf of <= 4 triangles, or List<Triangle>: ordered fold
+      bool bh = false; float bd = 0.0f, bt = 0.0f; uint32_t bi = 0;
+      for (uint32_t t = 0; t < o.ntri; t++) {
+        const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
+        if (!left_wins(bh, bd, th.hit, th.dist)) {
+          if (th.hit) { bh = true; bd = th.dist; bt = th.t; bi = o.tri_base + t; }
+          else { bh = false; bd = 0.0f; bt = 0.0f; bi = 0; }
+        }
+      }
+      hit[r] = bh; dist[r] = bd; tri[r] = bi;
+      pos[r] = ray_at(ray, bt);
+    }
+  }
+  if (xf && __ballot(hit[0] || hit[1] || hit[2]) != 0ull) {
+    const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      if (hit[r]) dist[r] = norm(mat_point(o.trans, pos[r]) - ow);
+  }
+}
+
+constexpr uint32_t kRetMiss = 0xFFFFFFFFu;
+SRT_DEV uint32_t pack_ret(const Hit& h) { return h.hit ? ((h.obj << 27) | h.tri) : kRetMiss; }
+SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
+  Hit h;
+  h.hit = id != kRetMiss;
+  h.dist = h.hit ? dist : 0.0f;
+  h.obj = h.hit ? (id >> 27) : 0;
+  h.tri = h.hit ? (id & 0x07FFFFFFu) : 0;
+  return h;
+}
+SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
+
 __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S, WaveParams P) {
-  extern __shared__ float4 lds_raw[];
-  Node* lnodes = reinterpret_cast<Node*>(lds_raw);
-  const uint32_t node_f4 = S.tlas_nodes * 2;  // 32 B per node
+  extern __shared__ float lds_f[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nobj = S.nobjects;
-  // per-wave tables: dist[k][r][lane], tri[k][r][lane]
-  float* tdist = reinterpret_cast<float*>(lds_raw + node_f4) + (size_t)wave * nobj * 3 * 64 * 2;
-  uint32_t* ttri = reinterpret_cast<uint32_t*>(tdist + nobj * 3 * 64);
-  for (uint32_t i = threadIdx.x; i < node_f4; i += blockDim.x) lds_raw[i] = reinterpret_cast<const float4*>(S.nodes)[i];
-  __syncthreads();
+  const uint32_t Q = S.use_bvh ? S.wave_q : 0u;
+  // per-wave sweep slots: [q][ray][field] x 64 lanes; field 0 = tin.x / ret.dist, 1 = tin.y / ret.id, 2 = cur_far_t.x
+  float* wl = lds_f + (size_t)wave * Q * 9 * 64 + lane;
+#define SLOT(q, r, f) wl[(((q) * 3 + (r)) * 3 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   Counters cnt;
@@ -149,89 +245,103 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S, WaveParams P) {
       continue;
     }
 
-    // ---------------- 2. trace the batch ----------------
+    // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
     cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
     const float rb0[3] = {kEps, kEps, cb0};
     const float rb1[3] = {FLT_MAX, FLT_MAX, cb1};
-
-    // phase 1: every object, wave-uniformly
-    for (uint32_t k = 0; k < nobj; k++) {
-      const Object& o = S.objects[k];
-      const bool xf = o.has_trans != 0;
-      V3 oorg = org;
-      if (xf) oorg = mat_point(o.itrans, org);
-      bool hit[3];
-      float dist[3];
-      uint32_t tri[3];
-      V3 pos[3];
+    Hit res[3];
+    if (Q == 0) {
+      // List<Object>::hit, or a BVH<Object> whose root is a leaf: ordered fold over every object
+#pragma unroll
+      for (int r = 0; r < 3; r++) res[r] = no_hit();
+      for (uint32_t k = 0; k < nobj; k++) {
+        bool h[3]; float dd[3]; uint32_t tt[3];
+        object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+#pragma unroll
+        for (int r = 0; r < 3; r++) fold(res[r], h[r], dd[r], k, tt[r]);
+      }
+    } else {
+      V3 inv[3];
+      float tx0[3], ty0[3];
+      unsigned long long fl[3] = {0ull, 0ull, 0ull};
 #pragma unroll
       for (int r = 0; r < 3; r++) {
-        Ray ray;
-        ray.o = oorg; ray.d = d[r]; ray.b0 = rb0[r]; ray.b1 = rb1[r];
-        if (xf) {                                       // Ray::transform with the shared origin
-          ray.d = mat_rotate(o.itrans, d[r]);
-          const float dn = norm(ray.d);
-          ray.b0 *= dn; ray.b1 *= dn;
-          ray.d = ray.d / dn;
+        inv[r] = v3(1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z);
+        const float dn = norm(d[r]);
+        tx0[r] = rb0[r] / dn; ty0[r] = rb1[r] / dn;   // Vec2 time_initial = dist_bounds / dir.norm()
+      }
+      // top-down: box tests, nearer/farther decision, hand `times` down
+      for (uint32_t q = 0; q < Q; q++) {
+        const WaveInterior& W = S.wave_tlas[q];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          float tx = tx0[r], ty = ty0[r];
+          if (q != 0) { tx = SLOT(q, r, 0); ty = SLOT(q, r, 1); }
+          float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
+          const bool hl = box_hit_inv(W.boxl, org, inv[r], t1x, t1y);
+          const bool hr = box_hit_inv(W.boxr, org, inv[r], t2x, t2y);
+          bool cl = false, hb = false;
+          float cx = rb0[r], cy = rb1[r], fx = rb0[r], fy = rb1[r];
+          if (hl && hr) {
+            hb = true;
+            if (t1x < t2x) { cl = true; cx = t1x; cy = t1y; fx = t2x; fy = t2y; }
+            else { cx = t2x; cy = t2y; fx = t1x; fy = t1y; }
+          } else if (hl) { cl = true; cx = t1x; cy = t1y; }
+          else { cx = t2x; cy = t2y; }
+          fl[r] |= (unsigned long long)((hl ? 1u : 0u) | (hr ? 2u : 0u) | (cl ? 4u : 0u) | (hb ? 8u : 0u)) << (4 * q);
+          SLOT(q, r, 2) = fx;
+          if (W.l_ref >= 0) { SLOT(W.l_ref, r, 0) = cl ? cx : fx; SLOT(W.l_ref, r, 1) = cl ? cy : fy; }
+          if (W.r_ref >= 0) { SLOT(W.r_ref, r, 0) = cl ? fx : cx; SLOT(W.r_ref, r, 1) = cl ? fy : cy; }
         }
-        tri[r] = 0;
-        if (o.kind == OBJ_SPHERE) {
-          const SphHit sh = sphere_hit(o.radius, ray);
-          hit[r] = sh.hit;
-          pos[r] = ray_at(ray, sh.t);
-          dist[r] = fabsf(norm(pos[r] - ray.o));
-        } else if (o.use_bvh && o.nnodes > 1) {         // a real BVH<Triangle>: per-lane walk
-          const Hit mh = mesh_hit<false>(S, o, ray, cnt);
-          hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
-          pos[r] = v3(0, 0, 0);
-          if (mh.hit && xf) { const TriHit th = tri_hit(S.tris[mh.tri], ray); pos[r] = ray_at(ray, th.t); }
-        } else {                                        // <= 4 triangles in one leaf, or List<Triangle>: ordered fold
-          bool bh = false; float bd = 0.0f, bt = 0.0f; uint32_t bi = 0;
-          for (uint32_t t = 0; t < o.ntri; t++) {
-            const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
-            if (!left_wins(bh, bd, th.hit, th.dist)) {
-              if (th.hit) { bh = true; bd = th.dist; bt = th.t; bi = o.tri_base + t; }
-              else { bh = false; bd = 0.0f; bt = 0.0f; bi = 0; }
+      }
+      // bottom-up: leaves are evaluated in place, interior children read back, then the visit rule + Trace::min
+      for (int q = (int)Q - 1; q >= 0; q--) {
+        const WaveInterior& W = S.wave_tlas[q];
+        Hit L[3], R[3];
+        if (W.l_ref >= 0) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) L[r] = unpack_ret(SLOT(W.l_ref, r, 0), __float_as_uint(SLOT(W.l_ref, r, 1)));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) L[r] = no_hit();
+          const uint32_t first = (uint32_t)~W.l_ref;
+          for (uint32_t k = first; k < first + W.l_cnt; k++) {
+            bool h[3]; float dd[3]; uint32_t tt[3];
+            object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+#pragma unroll
+            for (int r = 0; r < 3; r++) fold(L[r], h[r], dd[r], k, tt[r]);
+          }
+        }
+        if (W.r_ref >= 0) {
+#pragma unroll
+          for (int r = 0; r < 3; r++) R[r] = unpack_ret(SLOT(W.r_ref, r, 0), __float_as_uint(SLOT(W.r_ref, r, 1)));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; r++) R[r] = no_hit();
+          const uint32_t first = (uint32_t)~W.r_ref;
+          for (uint32_t k = first; k < first + W.r_cnt; k++) {
+            bool h[3]; float dd[3]; uint32_t tt[3];
+            object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+#pragma unroll
+            for (int r = 0; r < 3; r++) fold(R[r], h[r], dd[r], k, tt[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const uint32_t f = (uint32_t)(fl[r] >> (4 * q)) & 15u;
+          const bool cl = (f & 4u) != 0;
+          const Hit rc = cl ? L[r] : R[r];
+          const Hit rs = cl ? R[r] : L[r];
+          Hit ret = no_hit();
+          if (f & 3u) {
+            ret = rc;
+            const float farx = SLOT(q, r, 2);
+            if (farx < rc.dist || (!rc.hit && (f & 8u))) {       // student/bvh.inl:216
+              if (!left_wins(rc.hit, rc.dist, rs.hit, rs.dist)) ret = rs.hit ? rs : no_hit();
             }
           }
-          hit[r] = bh; dist[r] = bd; tri[r] = bi;
-          pos[r] = ray_at(ray, bt);
-        }
-      }
-      if (xf && __ballot(hit[0] || hit[1] || hit[2]) != 0ull) {
-        const V3 ow = mat_point(o.trans, oorg);         // Trace::transform: distance = |T*position - T*origin|
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-          if (hit[r]) dist[r] = norm(mat_point(o.trans, pos[r]) - ow);
-      }
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        tdist[(k * 3 + r) * 64 + lane] = dist[r];
-        ttri[(k * 3 + r) * 64 + lane] = hit[r] ? tri[r] : kMissTri;
-      }
-    }
-
-    // phase 2: replay find_closest_hit over the top-level tree, leaves are table lookups
-    Hit res[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      res[r].hit = false; res[r].dist = 0.0f; res[r].obj = 0; res[r].tri = 0;
-      const bool active = alive && (r == 2 || (r == 0 ? actA : actB));
-      if (__ballot(active) == 0ull) continue;
-      auto leaf = [&](uint32_t slot, Hit& acc) {
-        const uint32_t t = ttri[(slot * 3 + r) * 64 + lane];
-        fold(acc, t != kMissTri, tdist[(slot * 3 + r) * 64 + lane], slot, t);
-      };
-      if (active) {
-        Ray ray;
-        ray.o = org; ray.d = d[r]; ray.b0 = rb0[r]; ray.b1 = rb1[r];
-        if (S.use_bvh) {
-          if (S.tlas_nodes) {
-            const float dn = norm(ray.d);
-            res[r] = traverse<kMaxTlasDepth, false>(lnodes, ray, ray.b0 / dn, ray.b1 / dn, cnt, C_TLAS, leaf);
-          }
-        } else {
-          for (uint32_t k = 0; k < nobj; k++) leaf(k, res[r]);
+          if (q > 0) { SLOT(q, r, 0) = ret.dist; SLOT(q, r, 1) = __uint_as_float(pack_ret(ret)); }
+          else res[r] = ret;
         }
       }
     }
@@ -322,6 +432,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S, WaveParams P) {
     }
   }
 
+#undef SLOT
   unsigned long long r = cnt.v[C_RAYS];
   for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
   if (lane == 0) atomicAdd(P.ray_counter, r);
