@@ -155,6 +155,7 @@ def main():
 
     import srt_amd
     from soft_rendering_toolsets_amd import scenes
+    from soft_rendering_toolsets_amd.dist import TileShard, gather_tiles
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
     rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
@@ -174,11 +175,12 @@ def main():
     pt.set_camera(scene["camera"])
     pt.set_tiling(32, 32, rank, world)
     local_tiles, per_rank, fpt = pt.tile_info()
+    shard = TileShard(W, H, 32, 32, rank, world)
+    assert (local_tiles, per_rank, fpt) == (len(shard.local), shard.tiles_per_rank, shard.floats_per_tile)
 
     dev = torch.device("cuda", local_rank)
     tiles = torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev)
-    gathered = torch.zeros(world * per_rank * fpt, dtype=torch.float32, device=dev) if rank == 0 else None
-    gather_list = list(gathered.view(world, -1).unbind(0)) if (rank == 0 and world > 1) else None
+    gathered = torch.zeros(world * per_rank * fpt, dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
     image = torch.zeros(W * H * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     acc = torch.zeros(W * H * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
@@ -193,7 +195,7 @@ def main():
             e1.record()
             kernel_events.append((e0, e1))
         if world > 1:
-            dist.gather(tiles, gather_list, dst=0)     # RCCL over xGMI: tile radiance -> rank 0
+            gather_tiles(tiles, gathered, world, rank)  # one RCCL gather over xGMI: tile radiance -> rank 0
         if rank == 0:
             src = gathered if world > 1 else tiles
             pt.untile_device(stream, src.data_ptr(), image.data_ptr())

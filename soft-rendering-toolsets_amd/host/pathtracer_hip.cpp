@@ -1,0 +1,229 @@
+// See pathtracer_hip.h.  Host orchestration only: scene flattening through the C ABI, the reference's epoch
+// scheme, running-mean accumulation, progress / cancel.  Everything below trace_pixel is on the GPU.
+#include "pathtracer_hip.h"
+
+#include <cstring>
+
+#include "../gui/render.h"
+
+namespace PT {
+
+namespace {
+
+void check(int status, const char* what) {
+    if(status != SRT_OK) die("%s failed (%d): %s", what, status, srt_last_error());
+}
+
+void mat_to_array(const Mat4& m, float out[16]) {
+    for(int i = 0; i < 16; i++) out[i] = m.data[i];
+}
+
+srt_pt_material make_material(uint32_t type, Spectrum a, Spectrum b, float ior) {
+    srt_pt_material m;
+    m.type = type;
+    m.a[0] = a.r; m.a[1] = a.g; m.a[2] = a.b;
+    m.b[0] = b.r; m.b[1] = b.g; m.b[2] = b.b;
+    m.ior = ior;
+    return m;
+}
+
+} // namespace
+
+Pathtracer::Pathtracer(Gui::Widget_Render& gui, Vec2) : gui(gui) {
+    check(srt_pt_create(0, &ctx), "srt_pt_create");
+}
+
+Pathtracer::~Pathtracer() {
+    cancel();
+    srt_pt_destroy(ctx);
+}
+
+void Pathtracer::set_samples(size_t samples) {
+    n_samples = samples;
+}
+
+void Pathtracer::set_params(size_t w, size_t h, size_t samples, size_t depth, bool use_bvh) {
+    out_w = w;
+    out_h = h;
+    n_samples = samples;
+    max_depth = depth;
+    scene_use_bvh = use_bvh;
+    accumulator.resize(out_w, out_h);
+    epoch_buf.assign(3 * out_w * out_h, 0.0f);
+    check(srt_pt_set_params(ctx, (uint32_t)w, (uint32_t)h, (uint32_t)depth), "srt_pt_set_params");
+}
+
+// The object walk of the reference's build_scene, feeding the C ABI instead of PT::Object constructors.
+void Pathtracer::build_scene(Scene& layout_scene) {
+    check(srt_pt_scene_begin(ctx), "srt_pt_scene_begin");
+    bool warned = false;
+    layout_scene.for_items([&, this](Scene_Item& item) {
+        if(item.is<Scene_Object>()) {
+            Scene_Object& obj = item.get<Scene_Object>();
+            const Material::Options& opt = obj.material.opt;
+            if(!obj.opt.render) return;
+
+            srt_pt_material mat;
+            bool is_light = false;
+            switch(opt.type) {
+            case Material_Type::lambertian: mat = make_material(SRT_MAT_LAMBERTIAN, opt.albedo.to_linear(), {}, 1.0f); break;
+            case Material_Type::mirror: mat = make_material(SRT_MAT_MIRROR, opt.reflectance, {}, 1.0f); break;
+            case Material_Type::refract: mat = make_material(SRT_MAT_REFRACT, opt.transmittance, {}, opt.ior); break;
+            case Material_Type::glass: mat = make_material(SRT_MAT_GLASS, opt.transmittance, opt.reflectance, opt.ior); break;
+            case Material_Type::diffuse_light:
+                mat = make_material(SRT_MAT_DIFFUSE_LIGHT, obj.material.emissive(), {}, 1.0f);
+                is_light = true;
+                break;
+            default: return;
+            }
+            uint32_t idx = 0;
+            check(srt_pt_add_material(ctx, &mat, &idx), "srt_pt_add_material");
+
+            float T[16];
+            mat_to_array(obj.pose.transform(), T);
+            auto add_mesh = [&](const GL::Mesh& mesh, bool light) {
+                std::vector<float> pos, nrm;
+                for(const auto& v : mesh.verts()) {
+                    pos.insert(pos.end(), {v.pos.x, v.pos.y, v.pos.z});
+                    nrm.insert(nrm.end(), {v.norm.x, v.norm.y, v.norm.z});
+                }
+                const auto& idxs = mesh.indices();
+                check(srt_pt_add_mesh(ctx, pos.data(), nrm.data(), (uint32_t)mesh.verts().size(), idxs.data(),
+                                      (uint32_t)idxs.size(), T, idx, light ? 1 : 0),
+                      "srt_pt_add_mesh");
+            };
+            if(obj.is_shape()) {
+                if(is_light) {
+                    // The reference lights a shape through its triangle approximation (area_lights) but
+                    // intersects the analytic shape; the HIP path supports mesh lights only.
+                    if(!warned) warn("HIP path tracer: emissive analytic shapes are not supported; object skipped");
+                    warned = true;
+                    return;
+                }
+                check(srt_pt_add_sphere(ctx, obj.opt.shape.get<PT::Sphere>().radius, T, idx), "srt_pt_add_sphere");
+            } else {
+                add_mesh(obj.posed_mesh(), is_light);
+            }
+        } else if(item.is<Scene_Light>() || item.is<Scene_Particles>()) {
+            if(!warned) warn("HIP path tracer: delta/environment lights and particles are not on this path yet; ignored");
+            warned = true;
+        }
+    });
+    check(srt_pt_scene_commit(ctx, scene_use_bvh ? 1 : 0), "srt_pt_scene_commit");
+}
+
+void Pathtracer::accumulate(const float* epoch) {
+    std::lock_guard<std::mutex> lock(accumulator_mut);
+    accumulator_samples++;
+    for(size_t j = 0; j < out_h; j++) {
+        for(size_t i = 0; i < out_w; i++) {
+            Spectrum& s = accumulator.at(i, j);
+            const float* e = epoch + 3 * (j * out_w + i);
+            const Spectrum n(e[0], e[1], e[2]);
+            s += (n - s) * (1.0f / accumulator_samples);
+        }
+    }
+}
+
+void Pathtracer::worker(size_t samples_per_epoch, size_t first_sample) {
+    for(size_t s = 0; s < n_samples; s += samples_per_epoch) {
+        if(cancel_flag.load()) return;
+        size_t samples = (s + samples_per_epoch) > n_samples ? n_samples - s : samples_per_epoch;
+        check(srt_pt_render_epoch(ctx, seed, (uint32_t)(first_sample + s), (uint32_t)samples, epoch_buf.data()),
+              "srt_pt_render_epoch");
+        accumulate(epoch_buf.data());
+        size_t completed = completed_epochs++;
+        if(completed + 1 == total_epochs)
+            render_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_render0).count();
+    }
+}
+
+void Pathtracer::begin_render(Scene& layout_scene, const Camera& cam, bool add_samples) {
+    size_t n_threads = std::thread::hardware_concurrency();
+    size_t samples_per_epoch = std::max(size_t(1), n_samples / (n_threads * 10));
+
+    cancel();
+    total_epochs = n_samples / samples_per_epoch + !!(n_samples % samples_per_epoch);
+
+    if(!add_samples) {
+        accumulator.clear({});
+        accumulator_samples = 0;
+        samples_done = 0;
+        t_build0 = std::chrono::steady_clock::now();
+        build_scene(layout_scene);
+        build_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_build0).count();
+    }
+    t_render0 = std::chrono::steady_clock::now();
+
+    float iview[16];
+#ifdef SRT_CAMERA_HAS_IVIEW
+    mat_to_array(cam.get_iview(), iview);          // exact: the matrix Camera::generate_ray uses
+#else
+    mat_to_array(cam.get_view().inverse(), iview);  // util/camera.h has no iview getter; see INTEGRATION.md
+#endif
+    check(srt_pt_set_camera(ctx, iview, cam.get_fov(), cam.get_ar()), "srt_pt_set_camera");
+
+    const size_t first = samples_done;
+    samples_done += n_samples;
+    render_thread = std::thread([this, samples_per_epoch, first]() { worker(samples_per_epoch, first); });
+}
+
+void Pathtracer::cancel() {
+    cancel_flag = true;
+    if(render_thread.joinable()) render_thread.join();
+    completed_epochs = 0;
+    total_epochs = 0;
+    cancel_flag = false;
+}
+
+bool Pathtracer::in_progress() const {
+    return completed_epochs.load() < total_epochs;
+}
+
+float Pathtracer::progress() const {
+    return (float)completed_epochs.load() / (float)total_epochs;
+}
+
+std::pair<float, float> Pathtracer::completion_time() const {
+    return {(float)(build_ns.load() * 1e-9), (float)(render_ns.load() * 1e-9)};
+}
+
+const HDR_Image& Pathtracer::get_output() {
+    return accumulator;
+}
+
+const GL::Tex2D& Pathtracer::get_output_texture(float exposure) {
+    std::lock_guard<std::mutex> lock(accumulator_mut);
+    return accumulator.get_texture(exposure);
+}
+
+// Boxes of the BVH<Object> built for the GPU (same node arrays as the reference's, student/bvh.inl:324-372).
+size_t Pathtracer::visualize_bvh(GL::Lines& lines, GL::Lines& active, size_t level) {
+    std::vector<float> boxes(6 * 4096);
+    std::vector<uint32_t> links(4 * 4096);
+    long n = srt_pt_dump_bvh(ctx, -1, boxes.data(), links.data(), 4096, nullptr);
+    if(n <= 0) return 0;
+    size_t max_level = 0;
+    std::vector<std::pair<uint32_t, size_t>> stack{{0u, size_t(0)}};
+    while(!stack.empty()) {
+        auto [idx, lvl] = stack.back();
+        stack.pop_back();
+        max_level = std::max(max_level, lvl);
+        const float* b = &boxes[6 * idx];
+        Vec3 mn(b[0], b[1], b[2]), mx(b[3], b[4], b[5]);
+        Vec3 color = lvl == level ? Vec3(1.0f, 0.0f, 0.0f) : Vec3(1.0f);
+        GL::Lines& add = lvl == level ? active : lines;
+        const Vec3 c[8] = {Vec3(mn.x, mn.y, mn.z), Vec3(mx.x, mn.y, mn.z), Vec3(mn.x, mx.y, mn.z), Vec3(mn.x, mn.y, mx.z),
+                           Vec3(mx.x, mx.y, mn.z), Vec3(mn.x, mx.y, mx.z), Vec3(mx.x, mn.y, mx.z), Vec3(mx.x, mx.y, mx.z)};
+        const int e[12][2] = {{0, 1}, {0, 2}, {0, 3}, {7, 5}, {7, 6}, {7, 4}, {2, 4}, {2, 5}, {3, 6}, {3, 5}, {1, 4}, {1, 6}};
+        for(auto& ed : e) add.add(c[ed[0]], c[ed[1]], color);
+        const uint32_t l = links[4 * idx + 2], r = links[4 * idx + 3];
+        if(l != r) {
+            stack.push_back({l, lvl + 1});
+            stack.push_back({r, lvl + 1});
+        }
+    }
+    return max_level;
+}
+
+} // namespace PT
