@@ -276,7 +276,9 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT;
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
-      pt_wave_kernel<<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(device_scene(pt), P);
+      const DScene DS = device_scene(pt);
+      pt_wave_kernel<<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
+                                                                   DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
       SRT_HIP(hipGetLastError());
     }
     const int first = done == 0, last = done + chunk >= samples;

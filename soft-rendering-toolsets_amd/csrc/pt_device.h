@@ -152,6 +152,30 @@ SRT_DEV float srt_sincosf(float y, int want_cos) {
   }
   return __uint_as_float(0x7fc00000u);
 }
+// cosf(y) and sinf(y) together: both glibc routines reduce y the same way, so the reduction is shared.
+SRT_DEV void srt_sincosf2(float y, float& c, float& s) {
+  double x = (double)y;
+  const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+  if (top < 0x3f4u) {
+    if (top < 0x398u) { c = 1.0f; s = y; return; }
+    const double x2 = x * x;
+    c = sincos_poly(x, x2, false, 1);
+    s = sincos_poly(x, x2, false, 0);
+    return;
+  }
+  if (top < 0x42fu) {
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const int q = n & 3;
+    const double sg = (q == 1 || q == 2) ? -1.0 : 1.0;
+    const double xs = x * sg, x2 = x * x;
+    c = sincos_poly(xs, x2, (n & 2) != 0, n ^ 1);
+    s = sincos_poly(xs, x2, (n & 2) != 0, n);
+    return;
+  }
+  c = s = __uint_as_float(0x7fc00000u);
+}
 SRT_DEV float srt_cosf(float x) { return srt_sincosf(x, 1); }
 SRT_DEV float srt_sinf(float x) { return srt_sincosf(x, 0); }
 // (float)pow(x, 2) / (float)pow(1 - c, 5) with the float promoted to double (student/bsdf.cpp:17-21,47,150)

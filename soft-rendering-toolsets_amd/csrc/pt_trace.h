@@ -255,14 +255,25 @@ SRT_DEV float lambert_pdf(V3 out) {
   ct = std_min(std_max(ct, 0.0f), 1.0f);
   return ct / kPi;
 }
+// Samplers::Hemisphere::Cosine::sample (student/samplers.cpp:166-177)
+SRT_DEV V3 lambert_direction(Rng& rng) {
+  const float phi = rng.unit() * 2.0f * kPi;
+  const float cos_t = sqrtf(rng.unit());
+  const float sin_t = sqrtf(1 - cos_t * cos_t);
+  float cphi, sphi;
+  srt_sincosf2(phi, cphi, sphi);
+  return v3(cphi * sin_t, cos_t, sphi * sin_t);
+}
 SRT_DEV Scatter scatter(const Material& m, V3 out, Rng& rng) {
   Scatter r;
   if (m.type == 0) {                                   // BSDF_Lambertian::scatter, bsdf.cpp:69-87
     const float phi = rng.unit() * 2.0f * kPi;         // Hemisphere::Cosine::sample, samplers.cpp:166-177
     const float cos_t = sqrtf(rng.unit());
     const float sin_t = sqrtf(1 - cos_t * cos_t);
-    const float x = srt_cosf(phi) * sin_t;
-    const float z = srt_sinf(phi) * sin_t;
+    float cphi, sphi;
+    srt_sincosf2(phi, cphi, sphi);
+    const float x = cphi * sin_t;
+    const float z = sphi * sin_t;
     r.dir = v3(x, cos_t, z);
     r.atten = lambert_evaluate(m, out);
   } else if (m.type == 1) {                            // BSDF_Mirror::scatter, bsdf.cpp:119-126
@@ -331,10 +342,10 @@ SRT_DEV float light_pdf(const DScene& S, V3 from, V3 dir, Counters& cnt) {
     for (uint32_t li = 0; li < S.nlights; li++) {
       const Light& L = S.lights[li];
       float sum = 0.0f;
+      Ray tray = wray;
+      ray_transform(tray, L.pdfiT);             // Triangle::pdf transforms per triangle; same matrix, same result
       for (uint32_t t = 0; t < L.ntri; t++) {
         if (COUNT) cnt.v[C_LTRI]++;
-        Ray tray = wray;
-        ray_transform(tray, L.pdfiT);           // applied even when iT is the identity
         const uint32_t gi = L.tri_base + t;
         const TriHit th = tri_hit(S.tris[gi], tray);
         float p = 0.0f;

@@ -152,7 +152,7 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
     const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
 #pragma unroll
     for (int r = 0; r < 3; r++)
-      if (hit[r]) dist[r] = norm(mat_point(o.trans, pos[r]) - ow);
+      if (hit[r]) dist[r] = norm(mat_point_uniform(o.trans, pos[r]) - ow);
   }
 }
 
@@ -168,7 +168,20 @@ SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
 }
 SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
 
-__global__ __launch_bounds__(256) void pt_wave_kernel(DScene S, WaveParams P) {
+// Scene arrays are passed as separate `const T* __restrict__` kernel arguments (not inside DScene): only then can
+// the compiler prove that the stores to records / sample_out do not clobber them and turn the wave-uniform
+// scene reads into scalar loads (s_load_*), which is what keeps the sweeps off the vector memory path.
+__global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+                                                      const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
+                                                      const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
+                                                      const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
+                                                      const WaveInterior* __restrict__ a_wave, float* __restrict__ a_records,
+                                                      float* __restrict__ a_samples) {
+  DScene S = S_in;
+  S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
+  S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave;
+  WaveParams P = P_in;
+  P.records = a_records; P.sample_out = a_samples;
   extern __shared__ float lds_f[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nobj = S.nobjects;
@@ -401,25 +414,34 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S, WaveParams P) {
         const Frame fr = rotate_to(sf.normal);
         const V3 out_dir = unit(frame_to_local(fr, ray.o - sf.position));
         discrete = is_discrete(m.type);
-        const Scatter s1 = scatter(m, out_dir, rng);
+        // BSDF_Lambertian::evaluate / pdf depend on out_dir only: the reference's repeated calls
+        // (scatter twice, evaluate, pdf three times) all return these two values.
+        Scatter s1, s2;
+        if (m.type == 0) {
+          s1.atten = lambert_evaluate(m, out_dir);
+          pdf4 = lambert_pdf(out_dir);
+          s1.dir = lambert_direction(rng);
+        } else {
+          s1 = scatter(m, out_dir, rng);
+        }
         const V3 world_in = frame_to_world(fr, s1.dir);
         att = s1.atten;
         actA = true;
         actB = !discrete;
         V3 chosen = world_in;
         if (!discrete) {
-          pdf4 = lambert_pdf(out_dir);
           const V3 to_light = light_sample(S, sf.position, rng);
           chosen = rng.coin(0.5f) ? world_in : to_light;
           (void)rng.coin(0.0005f);
           pdf_area = light_pdf<false>(S, sf.position, to_light, cnt);
         }
-        const Scatter s2 = scatter(m, out_dir, rng);
+        if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
+        else s2 = scatter(m, out_dir, rng);
         const V3 world_in2 = frame_to_world(fr, s2.dir);
         float* rec = P.records + ((size_t)level * kRecFields) * P.nlanes + lane_global;
         const size_t st = P.nlanes;
         rec[3 * st] = s2.atten.r; rec[4 * st] = s2.atten.g; rec[5 * st] = s2.atten.b;
-        rec[6 * st] = discrete ? 0.0f : (1.0f / lambert_pdf(out_dir));
+        rec[6 * st] = discrete ? 0.0f : (1.0f / pdf4);
         rec[7 * st] = discrete ? 1.0f : 0.0f;
         level++;
         depth--;
