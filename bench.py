@@ -260,7 +260,7 @@ def main():
             "mean_radiance": mean_radiance,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "pt_epoch_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                "traffic": None, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                 "algorithmic_bytes_per_ray": bpr,
                 "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
                 "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d)",

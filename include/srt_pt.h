@@ -108,9 +108,13 @@ int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, con
                              uint32_t accumulator_samples);
 
 /* Kernel selection for render_epoch*: 0 = automatic (default), 1 = general per-lane kernel (any scene),
- * 2 = wave-uniform persistent kernel (scenes with at most 16 objects; fails otherwise).  Both produce
- * bit-identical images; the switch exists for A/B tests and profiling. */
+ * 2 = wave-uniform persistent kernel (scenes with at most 16 objects; fails otherwise), 3 = the same with
+ * in-kernel section stamps (diagnostic build, slower).  All produce bit-identical images; the switch exists
+ * for A/B tests and profiling. */
 int srt_pt_set_kernel(srt_pt* pt, int mode);
+/* Mode 3 only: shader-clock cycles summed over waves per loop section
+ * {refill, top-down sweep, leaf objects, combine, finish-direct, shade, terminate, 0}. */
+int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset);
 
 /* Rays (scene.hit calls) and camera samples traced by this context since the last reset. */
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);

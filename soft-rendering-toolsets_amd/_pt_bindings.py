@@ -35,6 +35,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_untile_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_accumulate_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint32]
     lib.srt_pt_set_kernel.argtypes = [c_void_p, c_int]
+    lib.srt_pt_section_cycles.argtypes = [c_void_p, c_void_p, c_int]
     lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -200,6 +201,12 @@ class Pathtracer:
     def set_kernel(self, mode: int) -> None:
         """0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel."""
         self._check(self._lib, self._lib.srt_pt_set_kernel(self._ctx, int(mode)))
+
+    def section_cycles(self, reset: bool = False) -> dict:
+        out = np.zeros(8, np.uint64)
+        self._check(self._lib, self._lib.srt_pt_section_cycles(self._ctx, _p(out), int(reset)))
+        names = ("refill", "top_down", "leaf_objects", "combine", "finish_direct", "shade", "terminate")
+        return dict(zip(names, (int(v) for v in out)))
 
     def ray_count(self, reset: bool = False):
         """(rays, camera_samples) traced by render_epoch* since the last reset (synchronizes the device)."""

@@ -253,8 +253,9 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const size_t lds = (size_t)4 * (F.use_bvh ? F.wave_tlas.size() : 0) * 9 * 64 * sizeof(float);  // 4 waves x Q x 3 rays x 3 fields
   if (pt->wave_blocks == 0 || pt->wave_lds != lds) {
     int per_cu = 0, cus = 0;
-    SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_wave_kernel, 256, lds));
+    SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_wave_kernel<false>, 256, lds));
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
     if (per_cu < 1) return srt::fail(SRT_ERR_UNSUPPORTED, "wave kernel does not fit on a CU (LDS %zu bytes)", lds);
     pt->wave_blocks = per_cu * cus;
@@ -266,19 +267,26 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 3)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_records, &pt->records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
-  if (!pt->d_queue) SRT_HIP(hipMalloc(&pt->d_queue, sizeof(unsigned long long)));
+  if (!pt->d_queue) {
+    SRT_HIP(hipMalloc(&pt->d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
+    SRT_HIP(hipMemset(pt->d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
+  }
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     WaveParams P;
     P.T = T; P.seed = seed; P.sample_base = sample_base + done; P.samples = n;
     P.total_units = px * n; P.nlanes = nlanes;
     P.sample_out = pt->d_samples; P.records = pt->d_records;
-    P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT;
+    P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = pt->d_queue + 1;
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
-      pt_wave_kernel<<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
-                                                                   DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
+      if (pt->kernel_mode == 3)
+        pt_wave_kernel<true><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
+                                                                           DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
+      else
+        pt_wave_kernel<false><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
+                                                                            DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
       SRT_HIP(hipGetLastError());
     }
     const int first = done == 0, last = done + chunk >= samples;
@@ -447,7 +455,7 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
 
 int srt_pt_set_kernel(srt_pt* pt, int mode) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_kernel: NULL context");
-  if (mode < 0 || mode > 2) return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (general) or 2 (wave-uniform)");
+  if (mode < 0 || mode > 3) return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (general), 2 (wave-uniform) or 3 (wave-uniform, stamped)");
   pt->kernel_mode = mode;
   return SRT_OK;
 }
@@ -462,7 +470,7 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
   const uint64_t lanes = (uint64_t)T.local_tiles * T.tile_w * T.tile_h;
   if (lanes * 64 > 0xffffffffull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32 sample units per launch");
   if (lanes) {
-    if (pt->kernel_mode == 2 && !wave_kernel_applies(pt))
+    if (pt->kernel_mode >= 2 && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "wave-uniform kernel needs 1..%u objects (scene has %zu)", kWaveMaxObjects,
                        pt->built.flat.objects.size());
     if (wave_kernel_applies(pt)) {
@@ -537,6 +545,20 @@ int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
       }
   }
+  return SRT_OK;
+}
+
+int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset) {
+  int st = need_device(pt, "srt_pt_section_cycles");
+  if (st != SRT_OK) return st;
+  if (!out) return srt::fail(SRT_ERR_INVALID, "srt_pt_section_cycles: NULL argument");
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  if (!pt->d_queue) return SRT_OK;
+  SRT_HIP(hipDeviceSynchronize());
+  unsigned long long h[ST_COUNT_];
+  SRT_HIP(hipMemcpy(h, pt->d_queue + 1, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < ST_COUNT_; i++) out[i] = h[i];
+  if (reset) SRT_HIP(hipMemset(pt->d_queue + 1, 0, sizeof h));
   return SRT_OK;
 }
 

@@ -208,56 +208,55 @@ SRT_DEV bool box_hit(const Node& nd, const Ray& ray, float& tx, float& ty) {
 // Triangle::hit (student/tri_mesh.cpp:32-111) on the precomputed {p0, e1, e2}.  Returns hit and, when hit,
 // distance = |t*d| and the barycentric triple (u, v, t).
 struct TriHit { bool hit; float dist, u, v, t; };
+// Straight-line form: every quantity is computed for every lane and the verdict is assembled from the same
+// comparisons the reference makes (det != 0; u, v, 1-u-v, t not negative; distance inside dist_bounds).  With
+// det == 0 the quotients are inf/NaN and simply unused.  No branches: the three rays of a batch and the
+// triangles of a leaf become independent instruction streams the scheduler can interleave.
 SRT_DEV TriHit tri_hit(const Tri& g, const Ray& ray) {
   TriHit h;
-  h.hit = true; h.dist = FLT_MIN; h.u = h.v = h.t = 0.0f;
   const V3 e1 = v3p(g.e1), e2 = v3p(g.e2);
   const V3 s = ray.o - v3p(g.p0);
   const V3 e1xd = cross(e1, ray.d);
   const float det = dot(e1xd, e2);
-  if (det != 0) {
-    const V3 sxe2 = cross(s, e2);
-    const float nu = -1.0f * dot(sxe2, ray.d);
-    const float nv = dot(e1xd, s);
-    const float nt = -1.0f * dot(sxe2, e1);
-    h.u = nu / det; h.v = nv / det; h.t = nt / det;
-    if (h.u < 0 || h.v < 0 || (1.0f - h.u - h.v) < 0 || h.t < 0) h.hit = false;
-    h.dist = fabsf(norm(ray.d * h.t));
-    if (h.dist < ray.b0 || h.dist > ray.b1) h.hit = false;
-  } else {
-    h.hit = false;
-  }
+  const V3 sxe2 = cross(s, e2);
+  const float nu = -1.0f * dot(sxe2, ray.d);
+  const float nv = dot(e1xd, s);
+  const float nt = -1.0f * dot(sxe2, e1);
+  h.u = nu / det; h.v = nv / det; h.t = nt / det;
+  const bool outside = (h.u < 0) || (h.v < 0) || ((1.0f - h.u - h.v) < 0) || (h.t < 0);
+  h.dist = fabsf(norm(ray.d * h.t));
+  const bool out_of_bounds = (h.dist < ray.b0) || (h.dist > ray.b1);
+  h.hit = (det != 0) && !outside && !out_of_bounds;
   return h;
 }
 
 // Sphere::hit (student/shapes.cpp:17-80).  The reference's unqualified sqrt(delta) is the double overload,
-// so the numerator sum and the quotient are fp64 before narrowing to t1/t2.
+// so the numerator sum and the quotient are fp64 before narrowing to t1/t2.  Straight-line form as above.
 struct SphHit { bool hit; float t; };
 SRT_DEV SphHit sphere_hit(float radius, const Ray& ray) {
-  SphHit h; h.hit = true; h.t = 0.0f;
+  SphHit h;
   const float a = norm2(ray.d);
   const float b = 2.0f * dot(ray.o, ray.d);
   const float c = norm2(ray.o) - radius * radius;
   const float delta = b * b - 4.0f * a * c;
-  if (delta > 0) {
-    const double m2od = (double)((-2.0f) * dot(ray.o, ray.d));
-    const double sq = sqrt((double)delta);
-    const double den = (double)(2.0f * norm2(ray.d));
-    const float t1 = (float)((m2od + sq) / den);
-    const float t2 = (float)((m2od - sq) / den);
-    bool v1 = !(t1 < 0), v2 = !(t2 < 0);
-    const float d1 = fabsf(norm(ray.d * t1));
-    const float d2 = fabsf(norm(ray.d * t2));
-    if (d1 < ray.b0 || d1 > ray.b1) v1 = false;
-    if (d2 < ray.b0 || d2 > ray.b1) v2 = false;
-    if (v1 && v2) h.t = std_min(t1, t2);
-    else if (!v1 && !v2) h.hit = false;
-    else h.t = v1 ? t1 : t2;
-  } else if (delta == 0) {
-    h.t = ((-2.0f) * dot(ray.o, ray.d)) / (2.0f * norm2(ray.d));
-  } else {
-    h.hit = false;
-  }
+  // delta > 0: two roots
+  const double m2od = (double)((-2.0f) * dot(ray.o, ray.d));
+  const double sq = sqrt((double)delta);
+  const double den = (double)(2.0f * norm2(ray.d));
+  const float t1 = (float)((m2od + sq) / den);
+  const float t2 = (float)((m2od - sq) / den);
+  bool v1 = !(t1 < 0), v2 = !(t2 < 0);
+  const float d1 = fabsf(norm(ray.d * t1));
+  const float d2 = fabsf(norm(ray.d * t2));
+  v1 = v1 && !(d1 < ray.b0 || d1 > ray.b1);
+  v2 = v2 && !(d2 < ray.b0 || d2 > ray.b1);
+  const float t_two = (v1 && v2) ? std_min(t1, t2) : (v1 ? t1 : t2);
+  const bool hit_two = v1 || v2;
+  // delta == 0: tangent, no validity checks in the reference
+  const float t_one = ((-2.0f) * dot(ray.o, ray.d)) / (2.0f * norm2(ray.d));
+  const bool two = delta > 0, one = delta == 0;
+  h.hit = two ? hit_two : one;
+  h.t = two ? (hit_two ? t_two : 0.0f) : (one ? t_one : 0.0f);
   return h;
 }
 

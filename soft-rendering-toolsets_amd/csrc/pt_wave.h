@@ -52,6 +52,7 @@ struct WaveParams {
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
+  unsigned long long* stamps;       // STAMP build only: per-section cycle sums
 };
 
 // pixel of local pixel index p (tile-major, 8x8 blocks inside a tile; same order as pt_epoch_kernel)
@@ -85,24 +86,28 @@ SRT_DEV V3 mat_point_uniform(const Mat4& m, V3 v) {
   return v3(o[0] / o[3], o[1] / o[3], o[2] / o[3]);
 }
 
-// BBox::hit with the reciprocal direction hoisted (the reference recomputes the same 1/dir per box).
+// BBox::hit with the reciprocal direction hoisted (the reference recomputes the same 1/dir per box), in
+// straight-line form: the two early-outs become one verdict, `times` is narrowed only on a hit.
 SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, float& ty) {
   const bool sx = inv.x < 0, sy = inv.y < 0, sz = inv.z < 0;
   float tmin = ((sx ? bx[3] : bx[0]) - o.x) * inv.x;
   float tmax = ((sx ? bx[0] : bx[3]) - o.x) * inv.x;
   const float tymin = ((sy ? bx[4] : bx[1]) - o.y) * inv.y;
   const float tymax = ((sy ? bx[1] : bx[4]) - o.y) * inv.y;
-  if ((tmin > tymax) || (tymin > tmax)) return false;
-  if (tymin > tmin) tmin = tymin;
-  if (tymax < tmax) tmax = tymax;
+  const bool miss_y = (tmin > tymax) || (tymin > tmax);
+  tmin = (tymin > tmin) ? tymin : tmin;
+  tmax = (tymax < tmax) ? tymax : tmax;
   const float tzmin = ((sz ? bx[5] : bx[2]) - o.z) * inv.z;
   const float tzmax = ((sz ? bx[2] : bx[5]) - o.z) * inv.z;
-  if ((tmin > tzmax) || (tzmin > tmax)) return false;
-  if (tzmin > tmin) tmin = tzmin;
-  if (tzmax < tmax) tmax = tzmax;
-  if (tmin >= tx && tmin <= ty) tx = tmin;
-  if (tmax >= tx && tmax <= ty) ty = tmax;
-  return true;
+  const bool miss_z = (tmin > tzmax) || (tzmin > tmax);
+  tmin = (tzmin > tmin) ? tzmin : tmin;
+  tmax = (tzmax < tmax) ? tzmax : tmax;
+  const bool hit = !miss_y && !miss_z;
+  const float nx = (tmin >= tx && tmin <= ty) ? tmin : tx;
+  const float ny = (tmax >= nx && tmax <= ty) ? tmax : ty;
+  tx = hit ? nx : tx;
+  ty = hit ? ny : ty;
+  return hit;
 }
 
 // Object::hit of object slot k for the three rays of a batch (shared origin), wave-uniformly: hit flag, the
@@ -139,10 +144,11 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       bool bh = false; float bd = 0.0f, bt = 0.0f; uint32_t bi = 0;
       for (uint32_t t = 0; t < o.ntri; t++) {
         const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
-        if (!left_wins(bh, bd, th.hit, th.dist)) {
-          if (th.hit) { bh = true; bd = th.dist; bt = th.t; bi = o.tri_base + t; }
-          else { bh = false; bd = 0.0f; bt = 0.0f; bi = 0; }
-        }
+        const bool keep = left_wins(bh, bd, th.hit, th.dist);   // ret = Trace::min(ret, hit)
+        bd = keep ? bd : (th.hit ? th.dist : 0.0f);
+        bt = keep ? bt : (th.hit ? th.t : 0.0f);
+        bi = keep ? bi : (th.hit ? o.tri_base + t : 0u);
+        bh = keep ? bh : th.hit;
       }
       hit[r] = bh; dist[r] = bd; tri[r] = bi;
       pos[r] = ray_at(ray, bt);
@@ -151,8 +157,11 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
   if (xf && __ballot(hit[0] || hit[1] || hit[2]) != 0ull) {
     const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-      if (hit[r]) dist[r] = norm(mat_point_uniform(o.trans, pos[r]) - ow);
+    for (int r = 0; r < 3; r++) {
+      const V3 p = hit[r] ? pos[r] : oorg;            // lanes without a hit transform a harmless point
+      const float wd = norm(mat_point_uniform(o.trans, p) - ow);
+      dist[r] = hit[r] ? wd : dist[r];
+    }
   }
 }
 
@@ -171,6 +180,11 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // Scene arrays are passed as separate `const T* __restrict__` kernel arguments (not inside DScene): only then can
 // the compiler prove that the stores to records / sample_out do not clobber them and turn the wave-uniform
 // scene reads into scalar loads (s_load_*), which is what keeps the sweeps off the vector memory path.
+//
+// STAMP = true is a diagnostic build: s_memtime deltas of the loop's sections are summed per wave and added to
+// P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
+enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
+template <bool STAMP>
 __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
@@ -186,6 +200,15 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nobj = S.nobjects;
   const uint32_t Q = S.use_bvh ? S.wave_q : 0u;
+  unsigned long long stamp_acc[ST_COUNT_] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_t = 0;
+  if (STAMP) stamp_t = __builtin_readcyclecounter();
+#define SECTION_END(i)                                                        \
+  if (STAMP) {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();             \
+    stamp_acc[i] += now_ - stamp_t;                                           \
+    stamp_t = now_;                                                           \
+  }
   // per-wave sweep slots: [q][ray][field] x 64 lanes; field 0 = tin.x / ret.dist, 1 = tin.y / ret.id, 2 = cur_far_t.x
   float* wl = lds_f + (size_t)wave * Q * 9 * 64 + lane;
 #define SLOT(q, r, f) wl[(((q) * 3 + (r)) * 3 + (f)) * 64]
@@ -257,6 +280,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
       if (queue_empty && chunk_next == chunk_end) break;
       continue;
     }
+    SECTION_END(ST_REFILL)
 
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
     cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
@@ -293,20 +317,20 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
           const bool hl = box_hit_inv(W.boxl, org, inv[r], t1x, t1y);
           const bool hr = box_hit_inv(W.boxr, org, inv[r], t2x, t2y);
-          bool cl = false, hb = false;
-          float cx = rb0[r], cy = rb1[r], fx = rb0[r], fy = rb1[r];
-          if (hl && hr) {
-            hb = true;
-            if (t1x < t2x) { cl = true; cx = t1x; cy = t1y; fx = t2x; fy = t2y; }
-            else { cx = t2x; cy = t2y; fx = t1x; fy = t1y; }
-          } else if (hl) { cl = true; cx = t1x; cy = t1y; }
-          else { cx = t2x; cy = t2y; }
+          // closer/second as in student/bvh.inl:186-209: both hit -> smaller entry time first (ties: right);
+          // one hit -> that one, the other child gets ray.dist_bounds as its `times`
+          const bool hb = hl && hr;
+          const bool cl = hb ? (t1x < t2x) : hl;
+          const float cx = cl ? t1x : t2x, cy = cl ? t1y : t2y;
+          const float fx = hb ? (cl ? t2x : t1x) : rb0[r];
+          const float fy = hb ? (cl ? t2y : t1y) : rb1[r];
           fl[r] |= (unsigned long long)((hl ? 1u : 0u) | (hr ? 2u : 0u) | (cl ? 4u : 0u) | (hb ? 8u : 0u)) << (4 * q);
           SLOT(q, r, 2) = fx;
           if (W.l_ref >= 0) { SLOT(W.l_ref, r, 0) = cl ? cx : fx; SLOT(W.l_ref, r, 1) = cl ? cy : fy; }
           if (W.r_ref >= 0) { SLOT(W.r_ref, r, 0) = cl ? fx : cx; SLOT(W.r_ref, r, 1) = cl ? fy : cy; }
         }
       }
+      SECTION_END(ST_TOPDOWN)
       // bottom-up: leaves are evaluated in place, interior children read back, then the visit rule + Trace::min
       for (int q = (int)Q - 1; q >= 0; q--) {
         const WaveInterior& W = S.wave_tlas[q];
@@ -339,6 +363,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
             for (int r = 0; r < 3; r++) fold(R[r], h[r], dd[r], k, tt[r]);
           }
         }
+        SECTION_END(ST_LEAVES)
 #pragma unroll
         for (int r = 0; r < 3; r++) {
           const uint32_t f = (uint32_t)(fl[r] >> (4 * q)) & 15u;
@@ -356,6 +381,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           if (q > 0) { SLOT(q, r, 0) = ret.dist; SLOT(q, r, 1) = __uint_as_float(pack_ret(ret)); }
           else res[r] = ret;
         }
+        SECTION_END(ST_COMBINE)
       }
     }
 
@@ -380,6 +406,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
         float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
         rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
       }
+      SECTION_END(ST_POST)
       // the indirect / camera ray decides how the path goes on (student/pathtracer.cpp:174-218)
       bool terminal = !res[2].hit;
       Spec e = spec(0, 0, 0);
@@ -405,7 +432,9 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
         float* so = P.sample_out + (size_t)unit_id * 3;
         so[0] = out.r; so[1] = out.g; so[2] = out.b;
         alive = false;
-      } else {
+      }
+      SECTION_END(ST_TERMINATE)
+      if (!terminal) {
         const Material& m = S.materials[mi];
         Ray ray;
         ray.o = org; ray.d = d[2]; ray.b0 = cb0; ray.b1 = cb1;
@@ -452,7 +481,11 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
         cb0 = kEps; cb1 = FLT_MAX;
       }
     }
+    SECTION_END(ST_SHADE)
   }
+  if (STAMP && lane == 0)
+    for (int i = 0; i < ST_COUNT_; i++) atomicAdd(&P.stamps[i], stamp_acc[i]);
+#undef SECTION_END
 
 #undef SLOT
   unsigned long long r = cnt.v[C_RAYS];
