@@ -39,6 +39,9 @@ struct RasterParams {
   uint32_t tile_s;   // samples per tile side
   uint32_t tiles_x, tiles_y;
   uint32_t nprims;
+  uint32_t coarse_tiles;         // a coarse bin is coarse_tiles x coarse_tiles tiles
+  uint32_t coarse_x, coarse_y;   // coarse grid
+  uint32_t list_stride;          // entries reserved per coarse bin (= nprims)
 };
 
 // stats slots (unsigned long long each)
@@ -107,11 +110,47 @@ __global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pass 1b: ordered coarse binning.  One workgroup per coarse bin (coarse_tiles^2 tiles) walks the whole
+// stream in order, 256 bounding boxes per step, and appends the indices of the overlapping primitives to
+// the bin's list with a block-wide ORDERED compaction (ballot + prefix), so every list is sorted by stream
+// position and painter's order survives.  A tile then scans its bin's list instead of the whole stream.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raster_coarse_bin(RasterParams P, const int4* __restrict__ bbox,
+                                                         uint32_t* __restrict__ lists, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t bin = blockIdx.x;
+  const int cx = (int)(bin % P.coarse_x), cy = (int)(bin / P.coarse_x);
+  const int span = (int)(P.coarse_tiles * P.tile_s);
+  const int x0 = cx * span, y0 = cy * span, x1 = x0 + span - 1, y1 = y0 + span - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* out = lists + (size_t)bin * P.list_stride;
+  uint32_t total = 0;
+  for (uint32_t base = 0; base < P.nprims; base += 256) {
+    const uint32_t idx = base + threadIdx.x;
+    int4 bb = make_int4(1, 1, 0, 0);
+    if (idx < P.nprims) bb = bbox[idx];
+    const bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+    const unsigned long long m = __ballot(ov);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t c = wave_cnt[w]; all += c; before += (w < wave) ? c : 0u; }
+    if (ov) out[total + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
+    total += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[bin] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pass 2: one wave per tile.
 // ---------------------------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
                                                      const int4* __restrict__ bbox,
+                                                     const uint32_t* __restrict__ lists,
+                                                     const uint32_t* __restrict__ counts,
                                                      uint32_t* __restrict__ rgba_out,
                                                      float4* __restrict__ samples_out,
                                                      unsigned long long* __restrict__ stats) {
@@ -138,18 +177,26 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
 
   unsigned long long n_tests = 0, n_frags = 0, n_pts = 0, n_bins = 0;
 
-  const uint32_t n = P.nprims;
+  // this tile's coarse bin: an ordered list of primitive indices
+  const uint32_t bin = (uint32_t)(ty / (int)P.coarse_tiles) * P.coarse_x + (uint32_t)(tx / (int)P.coarse_tiles);
+  const uint32_t* __restrict__ list = lists + (size_t)bin * P.list_stride;
+  const uint32_t n = counts[bin];
+  // software prefetch: the next 64 (index, bbox) pairs are in flight while the current ones are rasterized
+  uint32_t nidx = 0;
+  int4 nbb = make_int4(1, 1, 0, 0);
+  if ((uint32_t)lane < n) { nidx = list[lane]; nbb = bbox[nidx]; }
   for (uint32_t base = 0; base < n; base += WAVE) {
-    const uint32_t idx = base + lane;
-    int4 bb = make_int4(1, 1, 0, 0);
-    if (idx < n) bb = bbox[idx];
-    const bool overlaps = (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
+    const uint32_t myidx = nidx;
+    const int4 bb = nbb;
+    nbb = make_int4(1, 1, 0, 0);
+    if (base + WAVE + lane < n) { nidx = list[base + WAVE + lane]; nbb = bbox[nidx]; }
+    const bool overlaps = (base + lane < n) && (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
     unsigned long long mask = __ballot(overlaps);
 
     while (mask) {  // ascending bit order == stream order
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      const uint32_t pidx = __builtin_amdgcn_readfirstlane(base + b);
+      const uint32_t pidx = __builtin_amdgcn_readlane(myidx, b);
       const srt_prim* __restrict__ p = prims + pidx;
       // rectangle of this primitive inside the tile, tile-local sample coordinates
       const int rx0 = max(__builtin_amdgcn_readlane(bb.x, b), sx0) - sx0;
@@ -220,11 +267,10 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
               tile[si] = blend_over(tile[si], cr, cg, cb, one_minus_a);
             }
             if (STATS && hit) n_pts++;
-            __syncthreads();
           }
         }
       }
-      __syncthreads();  // LDS RMW of this primitive is visible before the next one starts
+      // no barrier: one wavefront owns the tile and its LDS operations execute in program order
     }
   }
   __syncthreads();
@@ -281,6 +327,8 @@ struct srt_raster {
   srt_prim* d_prims = nullptr;
   int4* d_bbox = nullptr;
   size_t d_cap = 0;
+  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists (coarse bins x list_stride)
+  uint32_t* d_counts = nullptr; size_t counts_cap = 0;
   uint32_t* d_rgba = nullptr;
   float4* d_samples = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -309,19 +357,43 @@ int upload_stream(srt_raster* r) {
 
 // Enqueue setup + tile kernels for the current stream on `s`.
 int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
-  const RasterParams& P = r->P;
+  RasterParams& P = r->P;
+  // coarse grid: bins of c x c tiles, c chosen so that the list storage (bins * nprims entries) stays <= 64 Mi entries
+  {
+    uint32_t c = 8;
+    auto bins_for = [&](uint32_t cc) { return (uint64_t)((P.tiles_x + cc - 1) / cc) * ((P.tiles_y + cc - 1) / cc); };
+    while (bins_for(c) * (uint64_t)(P.nprims ? P.nprims : 1) > (64ull << 20) && c < 65536) c *= 2;
+    P.coarse_tiles = c;
+    P.coarse_x = (P.tiles_x + c - 1) / c;
+    P.coarse_y = (P.tiles_y + c - 1) / c;
+    P.list_stride = P.nprims ? P.nprims : 1;
+    const size_t nb = (size_t)P.coarse_x * P.coarse_y;
+    if (r->counts_cap < nb) {
+      if (r->d_counts) SRT_HIP(hipFree(r->d_counts));
+      r->d_counts = nullptr;
+      SRT_HIP(hipMalloc(&r->d_counts, nb * sizeof(uint32_t)));
+      r->counts_cap = nb;
+    }
+    if (r->lists_cap < nb * P.list_stride) {
+      if (r->d_lists) SRT_HIP(hipFree(r->d_lists));
+      r->d_lists = nullptr;
+      SRT_HIP(hipMalloc(&r->d_lists, nb * P.list_stride * sizeof(uint32_t)));
+      r->lists_cap = nb * P.list_stride;
+    }
+  }
   if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (P.nprims) {
     const int bs = 256;
     raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_bbox,
                                                                       stats ? r->d_stats : nullptr);
   }
+  raster_coarse_bin<<<dim3(P.coarse_x * P.coarse_y), dim3(256), 0, s>>>(P, r->d_bbox, r->d_lists, r->d_counts);
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
   if (stats)
-    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_rgba, so, r->d_stats);
+    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_rgba, so, r->d_stats);
   else
-    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_rgba, so, nullptr);
+    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_rgba, so, nullptr);
   SRT_HIP(hipGetLastError());
   r->resolved = true;
   return SRT_OK;
@@ -363,6 +435,8 @@ int srt_raster_destroy(srt_raster* r) {
   (void)hipStreamSynchronize(r->stream);
   (void)hipFree(r->d_prims);
   (void)hipFree(r->d_bbox);
+  (void)hipFree(r->d_lists);
+  (void)hipFree(r->d_counts);
   (void)hipFree(r->d_rgba);
   (void)hipFree(r->d_samples);
   (void)hipFree(r->d_stats);
