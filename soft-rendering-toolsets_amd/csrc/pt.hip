@@ -264,7 +264,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const uint32_t chunk = 64;
   const uint32_t nlanes = (uint32_t)pt->wave_blocks * 256;
   int st;
-  if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 3)) != SRT_OK) return st;
+  if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_records, &pt->records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
   if (!pt->d_queue) {

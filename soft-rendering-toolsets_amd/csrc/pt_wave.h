@@ -48,7 +48,7 @@ struct WaveParams {
   uint32_t samples;          // samples per pixel in this launch
   uint32_t total_units;      // local_tiles * tile_w * tile_h * samples
   uint32_t nlanes;           // threads of the whole grid (record scratch stride)
-  float* sample_out;         // [unit][3]
+  float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
@@ -429,8 +429,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           L = dk + ind;
         }
         const Spec out = ((level == 0) ? e : spec(0, 0, 0)) + L;
-        float* so = P.sample_out + (size_t)unit_id * 3;
-        so[0] = out.r; so[1] = out.g; so[2] = out.b;
+        reinterpret_cast<float4*>(P.sample_out)[unit_id] = make_float4(out.r, out.g, out.b, 0.0f);  // one 16-B store
         alive = false;
       }
       SECTION_END(ST_TERMINATE)
@@ -507,9 +506,10 @@ __global__ void pt_reduce_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t sam
   Spec acc = spec(0, 0, 0);
   uint32_t sampled = 0;
   if (!first) { acc = spec(running[4 * (size_t)p], running[4 * (size_t)p + 1], running[4 * (size_t)p + 2]); sampled = __float_as_uint(running[4 * (size_t)p + 3]); }
-  const float* src = sample_out + (size_t)p * samples * 3;
+  const float4* src = reinterpret_cast<const float4*>(sample_out) + (size_t)p * samples;
   for (uint32_t s = 0; s < samples; s++) {
-    const Spec v = spec(src[3 * s], src[3 * s + 1], src[3 * s + 2]);
+    const float4 q = src[s];
+    const Spec v = spec(q.x, q.y, q.z);
     if (valid(v)) { acc = acc + v; sampled++; }
   }
   if (last) {
