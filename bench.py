@@ -162,9 +162,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # Rehearsal mode for a 1-GPU box: SRT_BENCH_REHEARSE=1 runs the N ranks on cuda:0 over gloo (tile
+    # buffers staged through host memory for the gather).  Never used for reported numbers.
+    rehearse = os.environ.get("SRT_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W = H = args.size
     spp = args.spp_per_step
@@ -194,7 +202,13 @@ def main():
         if timed:
             e1.record()
             kernel_events.append((e0, e1))
-        if world > 1:
+        if world > 1 and rehearse:
+            host = tiles.cpu()
+            ghost = torch.zeros(world * host.numel()) if rank == 0 else None
+            gather_tiles(host, ghost, world, rank)
+            if rank == 0:
+                gathered.copy_(ghost)
+        elif world > 1:
             gather_tiles(tiles, gathered, world, rank)  # one RCCL gather over xGMI: tile radiance -> rank 0
         if rank == 0:
             src = gathered if world > 1 else tiles
@@ -222,10 +236,11 @@ def main():
     rays, cams = pt.ray_count()
     kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if rehearse else dev
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max = float(t[0]), float(t[1])
-        c = torch.tensor([rays, cams], dtype=torch.int64, device=dev)
+        c = torch.tensor([rays, cams], dtype=torch.int64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_rays, total_cams = int(c[0]), int(c[1])
     else:
@@ -243,6 +258,8 @@ def main():
         rays_per_launch_rank0 = rays / args.steps
         achieved = bpr * rays_per_launch_rank0 / (kernel_ms * 1e-3) / 1e9
         mean_radiance = float(acc.mean().item())
+        import hashlib
+        image_sha = hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()[:16]
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -257,7 +274,7 @@ def main():
             "camera_samples_per_s": total_cams / elapsed, "rays": total_rays, "camera_samples": total_cams,
             "rays_per_camera_sample": total_rays / max(1, total_cams),
             "rays_counted": "every scene.hit the reference performs (no ray is elided)",
-            "mean_radiance": mean_radiance,
+            "mean_radiance": mean_radiance, "image_sha256_16": image_sha,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,

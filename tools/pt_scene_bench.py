@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: epoch time of a named scene with each kernel (1 = general per-lane, 2 = wave-uniform)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import srt_amd
+from soft_rendering_toolsets_amd import scenes
+
+name = sys.argv[1] if len(sys.argv) > 1 else "blob7"
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+if name.startswith("blob"):
+    scene = scenes.cornell_with_mesh(int(name[4:]), "glass")
+else:
+    scene = scenes.cornell_box(name)
+pt = srt_amd.Pathtracer(0)
+pt.set_params(size, size, spp, 8, True)
+t = time.perf_counter(); pt.build_scene(scene); print(f"build_scene {time.perf_counter()-t:.2f} s ({scene['name']})")
+pt.set_camera(scene["camera"])
+imgs = []
+for mode in (1, 2):
+    pt.set_kernel(mode)
+    pt.render_epoch(0, 0, 1)
+    pt.ray_count(reset=True)
+    t = time.perf_counter(); img = pt.render_epoch(0, 0, spp); dt = time.perf_counter() - t
+    rays, cams = pt.ray_count()
+    imgs.append(img)
+    print(f"mode {mode}: {dt*1e3:.1f} ms, {rays/dt/1e6:.0f} Mrays/s, {rays/cams:.2f} rays/sample")
+print("modes bit-identical:", np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32)))
+rng = np.random.default_rng(0); n = 20000
+xs, ys, ss = rng.integers(0, size, n), rng.integers(0, size, n), rng.integers(0, spp, n)
+pt.trace_samples(0, xs, ys, ss); c = pt.counters()
+print({k: round(v / c["rays"], 2) for k, v in c.items()})
