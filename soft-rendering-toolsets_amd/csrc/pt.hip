@@ -275,7 +275,8 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     WaveParams P;
     P.T = T; P.seed = seed; P.sample_base = sample_base + done; P.samples = n;
-    P.total_units = px * n; P.nlanes = nlanes;
+    P.groups = (n + kBurst - 1) / kBurst;
+    P.total_units = px * P.groups; P.nlanes = nlanes;
     P.sample_out = pt->d_samples; P.records = pt->d_records;
     P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = pt->d_queue + 1;
     if (n) {

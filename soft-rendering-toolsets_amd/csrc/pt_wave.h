@@ -23,10 +23,14 @@
 //   answer with no per-lane control flow at all.  Only meshes with a real BVH<Triangle> (more than one
 //   leaf) fall back to a per-lane walk inside the uniform object loop.
 //
-// Lanes run bounce cycles in lockstep: shade -> {BSDF-sampled direct ray, MIS direct ray, indirect ray} in
-// one batch -> shade ...  A lane whose path ends pulls the next (pixel, sample) unit from a global queue
-// (one atomic per 512 units per wave) and uses the indirect slot for its camera ray: persistent threads
-// with per-lane path regeneration, no tail of idle lanes.  Every sample's radiance is written to a
+// Lanes run cycles in lockstep; a cycle traces one batch of three rays that share their origin:
+//   bounce batch  {BSDF-sampled direct ray, MIS direct ray, indirect ray} of the lane's current path, or
+//   camera burst  the camera rays of the lane's next three samples (same pixel, consecutive sample indices).
+// After a burst the first sample's path goes on immediately, the other two camera hits are parked (one
+// packed dword each) and picked up — without another trace — as soon as the current path ends.  All three
+// slots of (almost) every batch therefore carry useful rays.  Work units are groups of three samples pulled
+// from a global queue (one atomic per 512 groups per wave): persistent threads with per-lane path
+// regeneration, no tail of idle lanes.  Every sample's radiance is written to a
 // per-unit buffer; pt_reduce_kernel then adds the samples of a pixel in sample order, exactly as do_trace
 // does (rays/pathtracer.cpp:216-226), so the image does not depend on which lane traced what.
 #ifndef SRT_PT_WAVE_H
@@ -37,7 +41,8 @@
 namespace srt {
 
 constexpr uint32_t kWaveMaxObjects = 16;
-constexpr uint32_t kChunk = 512;          // units a wave reserves per queue atomic
+constexpr uint32_t kChunk = 512;          // units (sample triples) a wave reserves per queue atomic
+constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
 constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
 
@@ -46,7 +51,8 @@ struct WaveParams {
   uint64_t seed;
   uint32_t sample_base;      // first sample index of this launch
   uint32_t samples;          // samples per pixel in this launch
-  uint32_t total_units;      // local_tiles * tile_w * tile_h * samples
+  uint32_t groups;           // units per pixel = ceil(samples / kBurst)
+  uint32_t total_units;      // local_tiles * tile_w * tile_h * groups
   uint32_t nlanes;           // threads of the whole grid (record scratch stride)
   float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
@@ -218,14 +224,19 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
   cnt.v[C_RAYS] = 0;
 
   // ---- persistent per-lane path state ----
-  bool alive = false;
-  uint32_t unit_id = 0, depth = 0, level = 0;
+  bool alive = false;                                    // the lane owns a unit that is not finished yet
+  bool burst = false;                                    // the batch in flight is a camera burst (else a bounce batch)
+  uint32_t px = 0, py = 0;                               // pixel of the unit
+  uint32_t s_first = 0, s_count = 0, s_cur = 0;          // samples [s_first, s_first + s_count) of the launch; current one
+  uint32_t pixel_slot = 0;                               // local pixel index (sample_out addressing)
+  uint32_t pend[2] = {kRetMiss, kRetMiss};               // parked camera hits of samples s_cur+1, s_cur+2 (burst order)
+  uint32_t depth = 0, level = 0;
   Rng rng;
   rng.state = 0; rng.inc = 1; rng.draws = 0;
   V3 org = v3(0, 0, 0);
-  V3 d[3] = {v3(0, 0, 1), v3(0, 0, 1), v3(0, 0, 1)};   // A: BSDF direct, B: MIS direct, C: indirect / camera
-  float cb0 = 0.0f, cb1 = 0.0f;                          // bounds of slot C (A and B are always [EPS_F, FLT_MAX])
-  bool actA = false, actB = false;
+  V3 d[3] = {v3(0, 0, 1), v3(0, 0, 1), v3(0, 0, 1)};   // bounce: A BSDF direct, B MIS direct, C indirect; burst: 3 camera rays
+  float cb0 = 0.0f, cb1 = 0.0f;                          // dist_bounds shared by the batch: [EPS_F, FLT_MAX] or the camera's [0, inf]
+  bool actA = false, actB = false;                       // bounce batch: slots in use (C always); burst: slots 1, 2 in use
   Spec att = spec(0, 0, 0);                              // s1.attenuation (== evaluate(out) for Lambertian)
   float pdf4 = 1.0f, pdf_area = 0.0f;
   bool discrete = false;
@@ -259,20 +270,30 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
       }
       if (my_unit != kMissTri) {
         uint32_t x, y;
-        unit_pixel(P.T, my_unit / P.samples, x, y);
+        unit_pixel(P.T, my_unit / P.groups, x, y);
         if (x < S.w && y < S.h) {                       // padding pixels of edge tiles are never read
           alive = true;
-          unit_id = my_unit;
+          burst = true;
+          px = x; py = y;
+          pixel_slot = my_unit / P.groups;
+          s_first = (my_unit % P.groups) * kBurst;
+          s_count = P.samples - s_first < kBurst ? P.samples - s_first : kBurst;
+          s_cur = s_first;
           level = 0;
           depth = S.max_depth;
-          rng.key(P.seed, y * S.w + x, P.sample_base + my_unit % P.samples);
-          const float jx = rng.unit() * 1.0f;           // trace_pixel, student/pathtracer.cpp:26-31
-          const float jy = rng.unit() * 1.0f;
-          const Ray cam = camera_ray(S, ((float)x + jx) / (float)S.w, ((float)y + jy) / (float)S.h);
-          org = cam.o;
-          d[2] = cam.d; cb0 = cam.b0; cb1 = cam.b1;
-          d[0] = cam.d; d[1] = cam.d;                   // inactive slots carry a harmless copy
-          actA = actB = false;
+          // camera rays of the unit's samples (trace_pixel, student/pathtracer.cpp:26-31); absent samples repeat the first
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const uint32_t sj = s_first + ((uint32_t)j < s_count ? (uint32_t)j : 0u);
+            rng.key(P.seed, y * S.w + x, P.sample_base + sj);
+            const float jx = rng.unit() * 1.0f;
+            const float jy = rng.unit() * 1.0f;
+            const Ray cam = camera_ray(S, ((float)x + jx) / (float)S.w, ((float)y + jy) / (float)S.h);
+            org = cam.o;                                // the same for every camera ray (iview * origin)
+            d[j] = cam.d; cb0 = cam.b0; cb1 = cam.b1;
+          }
+          actA = s_count > 1;                           // slot usage of a burst: ray j exists iff j < s_count
+          actB = s_count > 2;
         }
       }
     }
@@ -284,8 +305,8 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
 
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
     cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
-    const float rb0[3] = {kEps, kEps, cb0};
-    const float rb1[3] = {FLT_MAX, FLT_MAX, cb1};
+    const float rb0[3] = {cb0, cb0, cb0};
+    const float rb1[3] = {cb1, cb1, cb1};
     Hit res[3];
     if (Q == 0) {
       // List<Object>::hit, or a BVH<Object> whose root is a leaf: ordered fold over every object
@@ -385,39 +406,52 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
       }
     }
 
-    // ---------------- 3. finish the previous bounce, then shade or terminate ----------------
+    // ---------------- 3. finish the previous bounce / unpack the burst, then terminate or shade ----------------
     if (alive) {
-      if (actA) {                                       // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
-        Spec eA = spec(0, 0, 0), eB = spec(0, 0, 0);
-        if (res[0].hit) { const Spec e = emissive_of(S.materials[S.objects[res[0].obj].material]); if (luma(e) > 0.0f) eA = e; }
-        if (actB && res[1].hit) { const Spec e = emissive_of(S.materials[S.objects[res[1].obj].material]); if (luma(e) > 0.0f) eB = e; }
-        Spec radiance = spec(0, 0, 0);
-        if (discrete) {
-          const Spec direct = eA * att;
-          radiance = radiance + direct;
-        } else {
-          const Spec direct = (eA * att) * (1.0f / pdf4);
-          radiance = radiance + direct;
-          radiance = radiance - direct;
-          const float pdf = (pdf4 + pdf_area) / 2.0f;
-          const Spec d6 = (eB * att) * (1.0f / pdf);
-          radiance = radiance + d6;
+      uint32_t chit;                                    // packed closest hit that decides how the current path goes on
+      if (burst) {
+        // burst order: slot 0 = sample s_first (continues now), slots 1, 2 = the next samples (parked)
+        chit = pack_ret(res[0]);
+        pend[0] = pack_ret(res[1]);
+        pend[1] = pack_ret(res[2]);
+      } else {
+        if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
+          Spec eA = spec(0, 0, 0), eB = spec(0, 0, 0);
+          if (res[0].hit) { const Spec e = emissive_of(S.materials[S.objects[res[0].obj].material]); if (luma(e) > 0.0f) eA = e; }
+          if (actB && res[1].hit) { const Spec e = emissive_of(S.materials[S.objects[res[1].obj].material]); if (luma(e) > 0.0f) eB = e; }
+          Spec radiance = spec(0, 0, 0);
+          if (discrete) {
+            const Spec direct = eA * att;
+            radiance = radiance + direct;
+          } else {
+            const Spec direct = (eA * att) * (1.0f / pdf4);
+            radiance = radiance + direct;
+            radiance = radiance - direct;
+            const float pdf = (pdf4 + pdf_area) / 2.0f;
+            const Spec d6 = (eB * att) * (1.0f / pdf);
+            radiance = radiance + d6;
+          }
+          float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
+          rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
         }
-        float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-        rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+        chit = pack_ret(res[2]);
       }
       SECTION_END(ST_POST)
-      // the indirect / camera ray decides how the path goes on (student/pathtracer.cpp:174-218)
-      bool terminal = !res[2].hit;
+      // Resolve the current path; when it ends, the next parked camera hit (if any) takes over in the same cycle.
+      bool need_shade = false;
       Spec e = spec(0, 0, 0);
       uint32_t mi = 0;
-      if (!terminal) {
-        mi = (uint32_t)S.objects[res[2].obj].material;
-        e = emissive_of(S.materials[mi]);
-        if (luma(e) > 0.0f) terminal = true; else e = spec(0, 0, 0);
-        if (depth == 0) terminal = true;
-      }
-      if (terminal) {
+      for (int guard = 0; guard < 3 && !need_shade && alive; guard++) {
+        const Hit ch = unpack_ret(0.0f, chit);
+        bool terminal = !ch.hit;                         // student/pathtracer.cpp:174-218
+        e = spec(0, 0, 0);
+        if (!terminal) {
+          mi = (uint32_t)S.objects[ch.obj].material;
+          e = emissive_of(S.materials[mi]);
+          if (luma(e) > 0.0f) terminal = true; else e = spec(0, 0, 0);
+          if (depth == 0) terminal = true;
+        }
+        if (!terminal) { need_shade = true; break; }
         Spec L = spec(0, 0, 0);
         for (int k = (int)level - 1; k >= 0; k--) {
           const float* rec = P.records + ((size_t)k * kRecFields) * P.nlanes + lane_global;
@@ -429,15 +463,34 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           L = dk + ind;
         }
         const Spec out = ((level == 0) ? e : spec(0, 0, 0)) + L;
-        reinterpret_cast<float4*>(P.sample_out)[unit_id] = make_float4(out.r, out.g, out.b, 0.0f);  // one 16-B store
-        alive = false;
+        reinterpret_cast<float4*>(P.sample_out)[(size_t)pixel_slot * P.samples + s_cur] = make_float4(out.r, out.g, out.b, 0.0f);
+        // next sample of the unit: its camera hit is already known
+        s_cur++;
+        if (s_cur < s_first + s_count) {
+          chit = pend[0];
+          pend[0] = pend[1];
+          level = 0;
+          depth = S.max_depth;
+          burst = true;                                 // "the ray that led here was a camera ray"
+        } else {
+          alive = false;
+        }
       }
       SECTION_END(ST_TERMINATE)
-      if (!terminal) {
+      if (need_shade && alive) {
         const Material& m = S.materials[mi];
+        const Hit ch = unpack_ret(0.0f, chit);
         Ray ray;
         ray.o = org; ray.d = d[2]; ray.b0 = cb0; ray.b1 = cb1;
-        Surface sf = surface_of(S, res[2], ray);
+        if (level == 0) {
+          // a camera ray: regenerate it (and the RNG position after its two jitter draws) from the sample index
+          rng.key(P.seed, py * S.w + px, P.sample_base + s_cur);
+          const float jx = rng.unit() * 1.0f;
+          const float jy = rng.unit() * 1.0f;
+          ray = camera_ray(S, ((float)px + jx) / (float)S.w, ((float)py + jy) / (float)S.h);
+        }
+        burst = false;
+        Surface sf = surface_of(S, ch, ray);
         if (!is_sided(m.type) && dot(sf.normal, ray.d) > 0.0f) sf.normal = neg(sf.normal);
         const Frame fr = rotate_to(sf.normal);
         const V3 out_dir = unit(frame_to_local(fr, ray.o - sf.position));
