@@ -73,6 +73,30 @@ __global__ __launch_bounds__(64) void pt_epoch_kernel(DScene S, TileMap T, uint6
   }
 }
 
+// One lane per (pixel, sample) unit: the hardware's wave scheduler balances the load (scenes whose rays differ
+// wildly in cost, e.g. a 100k-triangle mesh inside the Cornell box); radiance goes to the per-unit buffer and
+// pt_reduce_kernel adds a pixel's samples in order.  Lanes of a wave hold consecutive samples of one pixel.
+__global__ __launch_bounds__(64) void pt_unit_kernel(DScene S, TileMap T, uint64_t seed, uint32_t sample_base, uint32_t samples,
+                                                     uint32_t total_units, float* __restrict__ sample_out,
+                                                     unsigned long long* __restrict__ ray_counter) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  Counters cnt;
+  cnt.v[C_RAYS] = 0;
+  if (u < total_units) {
+    uint32_t x, y;
+    unit_pixel(T, u / samples, x, y);
+    if (x < S.w && y < S.h) {
+      Rng rng;
+      rng.key(seed, y * S.w + x, sample_base + u % samples);
+      const Spec p = path_sample<false>(S, x, y, rng, cnt);
+      reinterpret_cast<float4*>(sample_out)[u] = make_float4(p.r, p.g, p.b, 0.0f);
+    }
+  }
+  unsigned long long r = cnt.v[C_RAYS];
+  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+  if ((threadIdx.x & 63) == 0 && r) atomicAdd(ray_counter, r);
+}
+
 // Explicit (x, y, sample) triples; instrumented when COUNT.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void pt_samples_kernel(DScene S, uint64_t seed, const uint32_t* __restrict__ xs,
@@ -162,7 +186,7 @@ struct srt_pt {
   // device copies
   Node* d_nodes = nullptr; Tri* d_tris = nullptr; TriNrm* d_nrm = nullptr; Object* d_objects = nullptr;
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
-  WaveInterior* d_wave = nullptr;
+  WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr;
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
@@ -208,7 +232,7 @@ DScene device_scene(const srt_pt* pt) {
   DScene S;
   S.nodes = pt->d_nodes; S.tris = pt->d_tris; S.tri_nrm = pt->d_nrm; S.objects = pt->d_objects;
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
-  S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size();
+  S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas;
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.cam = pt->cam; S.w = pt->w; S.h = pt->h; S.max_depth = pt->max_depth;
@@ -240,8 +264,12 @@ int ensure(T** buf, size_t* have, size_t need) {
 
 bool wave_kernel_applies(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
-  if (pt->kernel_mode == 1) return false;
-  return F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
+  if (pt->kernel_mode == 1 || pt->kernel_mode == 4) return false;
+  const bool fits = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
+  // auto mode: meshes with a real BVH<Triangle> make the lanes of a lockstep batch wait for the deepest walk;
+  // the per-lane kernel handles those scenes better
+  if (pt->kernel_mode == 0 && !F.blas_recs.empty()) return false;
+  return fits;
 }
 
 // One epoch with the wave-uniform persistent kernel: launches of <= 64 samples per pixel, each followed by the
@@ -284,10 +312,34 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
       const DScene DS = device_scene(pt);
       if (pt->kernel_mode == 3)
         pt_wave_kernel<true><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
-                                                                           DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
+                                                                           DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, P.sample_out);
       else
         pt_wave_kernel<false><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
-                                                                            DS.light_tris, DS.materials, DS.wave_tlas, P.records, P.sample_out);
+                                                                            DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, P.sample_out);
+      SRT_HIP(hipGetLastError());
+    }
+    const int first = done == 0, last = done + chunk >= samples;
+    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, pt->d_samples, pt->d_running, first, last, d_tiles_out);
+    SRT_HIP(hipGetLastError());
+    if (samples == 0) break;
+  }
+  return SRT_OK;
+}
+
+// One epoch with one lane per sample (general scenes): launches of <= 64 samples per pixel + ordered reduction.
+int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
+  const TileMap& T = pt->tiles;
+  const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
+  const uint32_t chunk = 64;
+  int st;
+  if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
+  if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
+  for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
+    const uint32_t n = samples - done < chunk ? samples - done : chunk;
+    const uint64_t units = (uint64_t)px * n;
+    if (n) {
+      pt_unit_kernel<<<dim3((unsigned)((units + 63) / 64)), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base + done, n,
+                                                                              (uint32_t)units, pt->d_samples, pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
     }
     const int first = done == 0, last = done + chunk >= samples;
@@ -334,7 +386,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipSetDevice(pt->device);
     (void)hipStreamSynchronize(pt->stream);
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
-    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave);
+    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
     (void)hipStreamDestroy(pt->stream);
@@ -412,7 +464,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
     if ((st = upload(&pt->d_nodes, F.nodes)) || (st = upload(&pt->d_tris, F.tris)) || (st = upload(&pt->d_nrm, F.tri_nrm)) ||
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
         (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
-        (st = upload(&pt->d_wave, F.wave_tlas)))
+        (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)))
       return st;
   }
   pt->committed = true;
@@ -456,7 +508,8 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
 
 int srt_pt_set_kernel(srt_pt* pt, int mode) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_kernel: NULL context");
-  if (mode < 0 || mode > 3) return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (general), 2 (wave-uniform) or 3 (wave-uniform, stamped)");
+  if (mode < 0 || mode > 4)
+    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped) or 4 (per-lane, lane per sample)");
   pt->kernel_mode = mode;
   return SRT_OK;
 }
@@ -471,11 +524,14 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
   const uint64_t lanes = (uint64_t)T.local_tiles * T.tile_w * T.tile_h;
   if (lanes * 64 > 0xffffffffull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32 sample units per launch");
   if (lanes) {
-    if (pt->kernel_mode >= 2 && !wave_kernel_applies(pt))
+    if ((pt->kernel_mode == 2 || pt->kernel_mode == 3) && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "wave-uniform kernel needs 1..%u objects (scene has %zu)", kWaveMaxObjects,
                        pt->built.flat.objects.size());
     if (wave_kernel_applies(pt)) {
       st = render_epoch_wave(pt, s, seed, sample_base, samples, d_tiles_out);
+      if (st != SRT_OK) return st;
+    } else if (pt->kernel_mode != 1) {
+      st = render_epoch_units(pt, s, seed, sample_base, samples, d_tiles_out);
       if (st != SRT_OK) return st;
     } else {
       const uint32_t blocks = (uint32_t)((lanes + 63) / 64);

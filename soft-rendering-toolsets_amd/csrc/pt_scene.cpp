@@ -361,6 +361,32 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
         o.nnodes = (uint32_t)B.blas[i].nodes.size();
         append_nodes(B.blas[i], &F);
         F.max_blas_depth = std::max(F.max_blas_depth, interior_depth(B.blas[i]));
+        {  // interior records of this BLAS
+          const std::vector<HostNode>& N = B.blas[i].nodes;
+          std::vector<int32_t> rank(N.size(), -1);
+          int32_t q = 0;
+          for (size_t n = 0; n < N.size(); n++)
+            if (N[n].l != N[n].r) rank[n] = q++;
+          o.rec_base = (uint32_t)F.blas_recs.size();
+          o.nrec = (uint32_t)q;
+          auto ref_of = [&](uint32_t child) -> int32_t {
+            const HostNode& c = N[child];
+            if (c.l != c.r) return rank[child];
+            return ~(int32_t)((c.start << 3) | (c.size & 7u));
+          };
+          for (size_t n = 0; n < N.size(); n++) {
+            if (N[n].l == N[n].r) continue;
+            WaveInterior wi;
+            const HostNode& a = N[N[n].l];
+            const HostNode& b = N[N[n].r];
+            for (int k = 0; k < 3; k++) { wi.boxl[k] = a.mn[k]; wi.boxl[3 + k] = a.mx[k]; wi.boxr[k] = b.mn[k]; wi.boxr[3 + k] = b.mx[k]; }
+            wi.l_ref = ref_of(N[n].l);
+            wi.r_ref = ref_of(N[n].r);
+            wi.l_cnt = a.size;
+            wi.r_cnt = b.size;
+            F.blas_recs.push_back(wi);
+          }
+        }
         append_triangles(in.mesh, &B.blas[i].prim);
       } else {
         append_triangles(in.mesh, nullptr);

@@ -48,7 +48,7 @@ struct Object {
   uint32_t tri_base, ntri;     // triangles [tri_base, tri_base + ntri)
   float radius;
   uint32_t id;                 // 1-based insertion index (diagnostics)
-  uint32_t pad[2];
+  uint32_t rec_base, nrec;     // BLAS interior records [rec_base, rec_base + nrec) in blas_recs; nrec == 0: the root is a leaf
   Mat4 trans, itrans;
 };
 static_assert(sizeof(Object) == 48 + 128, "object layout");
@@ -100,6 +100,9 @@ struct FlatScene {
   std::vector<Material> materials;
   uint32_t max_tlas_depth = 0, max_blas_depth = 0;  // interior-node nesting (stack frames needed)
   std::vector<WaveInterior> wave_tlas;              // empty when the root is a leaf (or in list mode)
+  // Per-mesh BVH<Triangle> as interior records (both child boxes in one 64-byte fetch).  Child refs: >= 0 interior
+  // rank inside the mesh's range; < 0 leaf, ~ref = (first triangle slot << 3) | triangle count (<= 4).
+  std::vector<WaveInterior> blas_recs;
 };
 
 // Input side (what the C ABI collects between scene_begin and scene_commit).

@@ -23,6 +23,7 @@ struct DScene {
   const LightTri* light_tris;
   const Material* materials;
   const WaveInterior* wave_tlas;   // interior nodes of the top-level tree in sweep order (pt_wave.h)
+  const WaveInterior* blas_recs;   // interior records of every BVH<Triangle>
   uint32_t wave_q;
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
@@ -133,21 +134,111 @@ SRT_DEV void fold(Hit& best, bool hit, float dist, uint32_t obj, uint32_t tri) {
   else { best.hit = false; best.dist = 0.0f; best.obj = 0; best.tri = 0; }
 }
 
+// BBox::hit on a record's child box with the reciprocal direction hoisted, straight-line form.
+SRT_DEV bool box_hit_rec(const float* __restrict__ bx, V3 o, V3 inv, float& tx, float& ty) {
+  const bool sx = inv.x < 0, sy = inv.y < 0, sz = inv.z < 0;
+  float tmin = ((sx ? bx[3] : bx[0]) - o.x) * inv.x;
+  float tmax = ((sx ? bx[0] : bx[3]) - o.x) * inv.x;
+  const float tymin = ((sy ? bx[4] : bx[1]) - o.y) * inv.y;
+  const float tymax = ((sy ? bx[1] : bx[4]) - o.y) * inv.y;
+  const bool miss_y = (tmin > tymax) || (tymin > tmax);
+  tmin = (tymin > tmin) ? tymin : tmin;
+  tmax = (tymax < tmax) ? tymax : tmax;
+  const float tzmin = ((sz ? bx[5] : bx[2]) - o.z) * inv.z;
+  const float tzmax = ((sz ? bx[2] : bx[5]) - o.z) * inv.z;
+  const bool miss_z = (tmin > tzmax) || (tzmin > tmax);
+  tmin = (tzmin > tmin) ? tzmin : tmin;
+  tmax = (tzmax < tmax) ? tzmax : tmax;
+  const bool hit = !miss_y && !miss_z;
+  const float nx = (tmin >= tx && tmin <= ty) ? tmin : tx;
+  const float ny = (tmax >= nx && tmax <= ty) ? tmax : ty;
+  tx = hit ? nx : tx;
+  ty = hit ? ny : ty;
+  return hit;
+}
+
+// find_closest_hit of one BVH<Triangle> over its interior records: one 64-byte fetch brings both child boxes,
+// leaves are folded in place, a stack frame is 16 bytes (after the nearer child returns, its result reuses
+// the slots of cur_far_t).  Same visit rule and Trace::min as traverse<>().
+struct RecFrame { int32_t second; float a, b; uint32_t flags; };  // flags: 1 hitboth, 2 nearer child done, 4 its hit
+template <int MAXD, bool COUNT>
+SRT_DEV Hit traverse_records(const DScene& S, const Object& o, const Ray& ray, float tx, float ty, Counters& cnt) {
+  const WaveInterior* __restrict__ recs = S.blas_recs + o.rec_base;
+  const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  RecFrame stack[MAXD];
+  int sp = 0;
+  int32_t cur = 0;
+  Hit ret;
+  for (;;) {
+    if (COUNT) cnt.v[C_BLAS]++;
+    ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+    bool descended = false;
+    if (cur < 0) {                                   // leaf: fold its triangles in order
+      const uint32_t packed = (uint32_t)~cur;
+      const uint32_t first = o.tri_base + (packed >> 3), n = packed & 7u;
+      for (uint32_t i = 0; i < n; i++) {
+        if (COUNT) cnt.v[C_TRI]++;
+        const TriHit th = tri_hit(S.tris[first + i], ray);
+        fold(ret, th.hit, th.dist, 0, first + i);
+      }
+    } else {
+      const WaveInterior W = recs[cur];
+      if (COUNT) cnt.v[C_BOX] += 2;
+      float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
+      const bool hl = box_hit_rec(W.boxl, ray.o, inv, t1x, t1y);
+      const bool hr = box_hit_rec(W.boxr, ray.o, inv, t2x, t2y);
+      if (hl || hr) {
+        const bool hb = hl && hr;
+        const bool cl = hb ? (t1x < t2x) : hl;
+        RecFrame& f = stack[sp++];
+        f.second = cl ? W.r_ref : W.l_ref;
+        f.a = hb ? (cl ? t2x : t1x) : ray.b0;
+        f.b = hb ? (cl ? t2y : t1y) : ray.b1;
+        f.flags = hb ? 1u : 0u;
+        cur = cl ? W.l_ref : W.r_ref;
+        tx = cl ? t1x : t2x;
+        ty = cl ? t1y : t2y;
+        descended = true;
+      }
+    }
+    if (descended) continue;
+    bool resume = false;
+    while (sp > 0) {
+      RecFrame& f = stack[sp - 1];
+      if (!(f.flags & 2u)) {
+        if (f.a < ret.dist || (!ret.hit && (f.flags & 1u))) {
+          cur = f.second; tx = f.a; ty = f.b;
+          f.flags |= 2u | (ret.hit ? 4u : 0u);
+          f.a = ret.dist; f.b = __uint_as_float(ret.tri);
+          resume = true;
+          break;
+        }
+        sp--;
+      } else {
+        if (left_wins((f.flags & 4u) != 0, f.a, ret.hit, ret.dist)) {
+          ret.hit = true; ret.dist = f.a; ret.obj = 0; ret.tri = __float_as_uint(f.b);
+        } else if (!ret.hit) {
+          ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+        }
+        sp--;
+      }
+    }
+    if (!resume) return ret;
+  }
+}
+
 // Closest triangle of one mesh in OBJECT space: Tri_Mesh::hit -> BVH<Triangle>::hit / List<Triangle>::hit.
-// Returns ids in Hit (tri = global triangle index) and the (u, v, t) of the winner through uvt.
+// Returns ids in Hit (tri = global triangle index).
 template <bool COUNT>
 SRT_DEV Hit mesh_hit(const DScene& S, const Object& o, const Ray& oray, Counters& cnt) {
   Hit best; best.hit = false; best.dist = 0.0f; best.obj = 0; best.tri = 0;
+  if (o.use_bvh && o.nrec > 0) {
+    const float dn = norm(oray.d);
+    return traverse_records<kMaxBlasDepth, COUNT>(S, o, oray, oray.b0 / dn, oray.b1 / dn, cnt);  // times = dist_bounds / dir.norm()
+  }
   if (o.use_bvh) {
     if (o.nnodes == 0) return best;
-    const float dn = norm(oray.d);
-    const float tx = oray.b0 / dn, ty = oray.b1 / dn;  // Vec2 time_initial = dist_bounds / dir.norm()
-    auto leaf = [&](uint32_t slot, Hit& acc) {
-      if (COUNT) cnt.v[C_TRI]++;
-      const TriHit th = tri_hit(S.tris[o.tri_base + slot], oray);
-      fold(acc, th.hit, th.dist, 0, o.tri_base + slot);
-    };
-    return traverse<kMaxBlasDepth, COUNT>(S.nodes + o.node_base, oray, tx, ty, cnt, C_BLAS, leaf);
+    if (COUNT) cnt.v[C_BLAS]++;                      // the root is a leaf holding every triangle
   }
   for (uint32_t t = 0; t < o.ntri; t++) {
     if (COUNT) cnt.v[C_TRI]++;

@@ -141,7 +141,7 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       hit[r] = sh.hit;
       pos[r] = ray_at(ray, sh.t);
       dist[r] = fabsf(norm(pos[r] - ray.o));
-    } else if (o.use_bvh && o.nnodes > 1) {           // a real BVH<Triangle>: per-lane walk
+    } else if (o.use_bvh && o.nrec > 0) {             // a real BVH<Triangle>: per-lane walk
       const Hit mh = mesh_hit<false>(S, o, ray, cnt);
       hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
       pos[r] = v3(0, 0, 0);
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
-                                                      const WaveInterior* __restrict__ a_wave, float* __restrict__ a_records,
-                                                      float* __restrict__ a_samples) {
+                                                      const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
+                                                      float* __restrict__ a_records, float* __restrict__ a_samples) {
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
-  S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave;
+  S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
   WaveParams P = P_in;
   P.records = a_records; P.sample_out = a_samples;
   extern __shared__ float lds_f[];

@@ -201,13 +201,13 @@ def test_wave_kernel_equals_general_kernel_and_oracle(srt, name, use_bvh, wh, sp
     want = H.OraclePT(scene, w, h, depth, use_bvh).epoch(5, 9, spp)
     pt = make_pt(srt, scene, w, h, depth, use_bvh)
     rays = []
-    for mode in (1, 2):
+    for mode in (1, 2, 4):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         img = pt.render_epoch(5, 9, spp)
         assert bits_equal(img, want), f"kernel mode {mode} differs from the oracle"
         rays.append(pt.ray_count()[0])
-    assert rays[0] == rays[1] > 0      # both kernels trace exactly the same rays
+    assert rays[0] == rays[1] == rays[2] > 0      # all kernels trace exactly the same rays
     pt.set_kernel(2)
     pt.set_tiling(16, 8, 1, 3)         # sharded: rank 1 of 3
     part = np.full((h, w, 3), -1.0, np.float32)
