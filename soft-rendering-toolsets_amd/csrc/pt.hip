@@ -194,7 +194,7 @@ struct srt_pt {
   float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
   float* d_running = nullptr; size_t running_floats = 0;   // wave kernel: (sum, count) across launches
   unsigned long long* d_queue = nullptr;                   // wave kernel: queue head
-  int wave_blocks = 0; size_t wave_lds = 0;
+  int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1;
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
@@ -279,11 +279,14 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
   const size_t lds = (size_t)4 * (F.use_bvh ? F.wave_tlas.size() : 0) * 9 * 64 * sizeof(float);  // 4 waves x Q x 3 rays x 3 fields
-  if (pt->wave_blocks == 0 || pt->wave_lds != lds) {
+  if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode) {
+    pt->wave_mode = pt->kernel_mode;
     int per_cu = 0, cus = 0;
-    SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SRT_HIP(hipFuncSetAttribute((const void*)pt_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_wave_kernel<false>, 256, lds));
+    const bool blas = !F.blas_recs.empty();
+    const void* kern = pt->kernel_mode == 3 ? (blas ? (const void*)pt_wave_kernel<true, true> : (const void*)pt_wave_kernel<true, false>)
+                                            : (blas ? (const void*)pt_wave_kernel<false, true> : (const void*)pt_wave_kernel<false, false>);
+    SRT_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
     if (per_cu < 1) return srt::fail(SRT_ERR_UNSUPPORTED, "wave kernel does not fit on a CU (LDS %zu bytes)", lds);
     pt->wave_blocks = per_cu * cus;
@@ -310,12 +313,14 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
-      if (pt->kernel_mode == 3)
-        pt_wave_kernel<true><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
-                                                                           DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, P.sample_out);
-      else
-        pt_wave_kernel<false><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,
-                                                                            DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, P.sample_out);
+#define SRT_LAUNCH_WAVE(STAMP_, BLAS_)                                                                                        \
+  pt_wave_kernel<STAMP_, BLAS_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
+                                                                              DS.lights, DS.light_tris, DS.materials,           \
+                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out)
+      const bool blas = !F.blas_recs.empty();
+      if (pt->kernel_mode == 3) { if (blas) SRT_LAUNCH_WAVE(true, true); else SRT_LAUNCH_WAVE(true, false); }
+      else { if (blas) SRT_LAUNCH_WAVE(false, true); else SRT_LAUNCH_WAVE(false, false); }
+#undef SRT_LAUNCH_WAVE
       SRT_HIP(hipGetLastError());
     }
     const int first = done == 0, last = done + chunk >= samples;

@@ -118,6 +118,9 @@ SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, 
 
 // Object::hit of object slot k for the three rays of a batch (shared origin), wave-uniformly: hit flag, the
 // world distance Trace::transform recomputes, and the winning triangle (global index).
+// HAS_BLAS = false compiles the per-lane BVH<Triangle> walk out (the host picks that build when every mesh is a
+// single leaf, e.g. the Cornell box): the walk's registers would otherwise halve the occupancy of the common path.
+template <bool HAS_BLAS>
 SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
                           Counters& cnt, bool* hit, float* dist, uint32_t* tri) {
   const Object& o = S.objects[k];
@@ -141,7 +144,7 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       hit[r] = sh.hit;
       pos[r] = ray_at(ray, sh.t);
       dist[r] = fabsf(norm(pos[r] - ray.o));
-    } else if (o.use_bvh && o.nrec > 0) {             // a real BVH<Triangle>: per-lane walk
+    } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) { // a real BVH<Triangle>: per-lane walk
       const Hit mh = mesh_hit<false>(S, o, ray, cnt);
       hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
       pos[r] = v3(0, 0, 0);
@@ -190,7 +193,7 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // STAMP = true is a diagnostic build: s_memtime deltas of the loop's sections are summed per wave and added to
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
-template <bool STAMP>
+template <bool STAMP, bool HAS_BLAS>
 __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
       for (int r = 0; r < 3; r++) res[r] = no_hit();
       for (uint32_t k = 0; k < nobj; k++) {
         bool h[3]; float dd[3]; uint32_t tt[3];
-        object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+        object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
         for (int r = 0; r < 3; r++) fold(res[r], h[r], dd[r], k, tt[r]);
       }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           const uint32_t first = (uint32_t)~W.l_ref;
           for (uint32_t k = first; k < first + W.l_cnt; k++) {
             bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
             for (int r = 0; r < 3; r++) fold(L[r], h[r], dd[r], k, tt[r]);
           }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           const uint32_t first = (uint32_t)~W.r_ref;
           for (uint32_t k = first; k < first + W.r_cnt; k++) {
             bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
             for (int r = 0; r < 3; r++) fold(R[r], h[r], dd[r], k, tt[r]);
           }
