@@ -24,7 +24,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_uint
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrt_hip.so")
+LIB_PATH = os.environ.get("SRT_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsrt_hip.so")  # env override: A/B builds
 
 # One record of the ordered primitive stream (include/srt_raster.h: srt_prim, 48 bytes).
 PRIM_DTYPE = np.dtype(

@@ -194,7 +194,7 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
 template <bool STAMP, bool HAS_BLAS>
-__global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+__global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
@@ -218,9 +218,12 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
     stamp_acc[i] += now_ - stamp_t;                                           \
     stamp_t = now_;                                                           \
   }
-  // per-wave sweep slots: [q][ray][field] x 64 lanes; field 0 = tin.x / ret.dist, 1 = tin.y / ret.id, 2 = cur_far_t.x
-  float* wl = lds_f + (size_t)wave * Q * 9 * 64 + lane;
-#define SLOT(q, r, f) wl[(((q) * 3 + (r)) * 3 + (f)) * 64]
+  // per-wave sweep slots: [q][ray][field] x 64 lanes.  A slot is reused as it goes through the sweeps:
+  //   written by the parent   field 0 = tin.x, field 1 = tin.y      (top-down, before step q)
+  //   after step q            field 0 = cur_far_t.x of node q        (tin is dead once read)
+  //   after bottom-up step q  field 0 = ret.dist, field 1 = ret.id   (read by the parent)
+  float* wl = lds_f + (size_t)wave * Q * 6 * 64 + lane;
+#define SLOT(q, r, f) wl[(((q) * 3 + (r)) * 2 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   Counters cnt;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           const float fx = hb ? (cl ? t2x : t1x) : rb0[r];
           const float fy = hb ? (cl ? t2y : t1y) : rb1[r];
           fl[r] |= (unsigned long long)((hl ? 1u : 0u) | (hr ? 2u : 0u) | (cl ? 4u : 0u) | (hb ? 8u : 0u)) << (4 * q);
-          SLOT(q, r, 2) = fx;
+          SLOT(q, r, 0) = fx;
           if (W.l_ref >= 0) { SLOT(W.l_ref, r, 0) = cl ? cx : fx; SLOT(W.l_ref, r, 1) = cl ? cy : fy; }
           if (W.r_ref >= 0) { SLOT(W.r_ref, r, 0) = cl ? fx : cx; SLOT(W.r_ref, r, 1) = cl ? fy : cy; }
         }
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void pt_wave_kernel(DScene S_in, WaveParams P_
           Hit ret = no_hit();
           if (f & 3u) {
             ret = rc;
-            const float farx = SLOT(q, r, 2);
+            const float farx = SLOT(q, r, 0);
             if (farx < rc.dist || (!rc.hit && (f & 8u))) {       // student/bvh.inl:216
               if (!left_wins(rc.hit, rc.dist, rs.hit, rs.dist)) ret = rs.hit ? rs : no_hit();
             }
