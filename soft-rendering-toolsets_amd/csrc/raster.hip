@@ -192,38 +192,52 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
     if (base + WAVE + lane < n) { nidx = list[base + WAVE + lane]; nbb = bbox[nidx]; }
     const bool overlaps = (base + lane < n) && (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
     unsigned long long mask = __ballot(overlaps);
+    // every overlapping lane fetches ITS primitive record now (three 16-byte loads in flight per lane); the ordered
+    // loop below then reads records lane by lane with v_readlane instead of paying one memory round trip per primitive
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
+    if (overlaps) {
+      const uint4* __restrict__ pp = reinterpret_cast<const uint4*>(prims + myidx);
+      q0 = pp[0]; q1 = pp[1]; q2 = pp[2];
+    }
 
     while (mask) {  // ascending bit order == stream order
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      const uint32_t pidx = __builtin_amdgcn_readlane(myidx, b);
-      const srt_prim* __restrict__ p = prims + pidx;
+      // srt_prim: {kind, reserved, v[6 floats | 2 doubles], rgba[4]}
+      const uint32_t kind = __builtin_amdgcn_readlane(q0.x, b);
+      const uint32_t w2 = __builtin_amdgcn_readlane(q0.z, b), w3 = __builtin_amdgcn_readlane(q0.w, b);
+      const uint32_t w4 = __builtin_amdgcn_readlane(q1.x, b), w5 = __builtin_amdgcn_readlane(q1.y, b);
+      const uint32_t w6 = __builtin_amdgcn_readlane(q1.z, b), w7 = __builtin_amdgcn_readlane(q1.w, b);
       // rectangle of this primitive inside the tile, tile-local sample coordinates
       const int rx0 = max(__builtin_amdgcn_readlane(bb.x, b), sx0) - sx0;
       const int ry0 = max(__builtin_amdgcn_readlane(bb.y, b), sy0) - sy0;
       const int rx1 = min(__builtin_amdgcn_readlane(bb.z, b), sx1) - sx0;
       const int ry1 = min(__builtin_amdgcn_readlane(bb.w, b), sy1) - sy0;
-      const float cr = p->rgba[0], cg = p->rgba[1], cb = p->rgba[2];
-      const float one_minus_a = 1 - p->rgba[3];
+      const float cr = __uint_as_float(__builtin_amdgcn_readlane(q2.x, b));
+      const float cg = __uint_as_float(__builtin_amdgcn_readlane(q2.y, b));
+      const float cb = __uint_as_float(__builtin_amdgcn_readlane(q2.z, b));
+      const float one_minus_a = 1 - __uint_as_float(__builtin_amdgcn_readlane(q2.w, b));
       if (STATS) n_bins++;
 
-      if (p->kind == SRT_PRIM_TRIANGLE) {
-        const double ax = (double)p->v.tri[0], ay = (double)p->v.tri[1];
-        const double bx = (double)p->v.tri[2], by = (double)p->v.tri[3];
-        const double cx = (double)p->v.tri[4], cy = (double)p->v.tri[5];
+      if (kind == SRT_PRIM_TRIANGLE) {
+        const double ax = (double)__uint_as_float(w2), ay = (double)__uint_as_float(w3);
+        const double bx = (double)__uint_as_float(w4), by = (double)__uint_as_float(w5);
+        const double cx = (double)__uint_as_float(w6), cy = (double)__uint_as_float(w7);
         const double e0x = bx - ax, e0y = by - ay;  // t0t1
         const double e1x = cx - bx, e1y = cy - by;  // t1t2
         const double e2x = ax - cx, e2y = ay - cy;  // t2t0
         const double d0x = px - ax, d1x = px - bx, d2x = px - cx;
+        // e.y * (p.x - v.x) does not depend on the row: one fp64 product per edge per primitive instead of per sample
+        const double k0 = e0y * d0x, k1 = e1y * d1x, k2 = e2y * d2x;
         const bool xin = (lx >= rx0) && (lx <= rx1);
         if (STATS) n_tests += (unsigned long long)(rx1 - rx0 + 1) * (unsigned long long)(ry1 - ry0 + 1);
 
         for (int row = ry0 + lrow; row <= ry1; row += 2) {
           const double py = rowy[row];
           const double d0y = py - ay, d1y = py - by, d2y = py - cy;
-          const float c1 = (float)(e0x * d0y - e0y * d0x);
-          const float c2 = (float)(e1x * d1y - e1y * d1x);
-          const float c3 = (float)(e2x * d2y - e2y * d2x);
+          const float c1 = (float)(e0x * d0y - k0);
+          const float c2 = (float)(e1x * d1y - k1);
+          const float c3 = (float)(e2x * d2y - k2);
           const float p12 = c1 * c2, p23 = c2 * c3, p13 = c1 * c3;
           const bool ccw = (p12 >= 0) && (p23 >= 0) && (p13 >= 0);
           const bool cw = (p12 <= 0) && (p23 <= 0) && (p13 <= 0);
@@ -236,8 +250,8 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
         }
       } else {  // SRT_PRIM_POINT
         const uint32_t sr = P.sr;
-        const double fx = p->v.point[0] * (double)sr;
-        const double fy = p->v.point[1] * (double)sr;
+        const double fx = __hiloint2double((int)w3, (int)w2) * (double)sr;   // v.point[0], v.point[1]
+        const double fy = __hiloint2double((int)w5, (int)w4) * (double)sr;
         // Distinct (i,j) land on distinct samples unless truncation toward zero folds two of them
         // onto column/row 0 (fx+i in (-1,0)); then the block must be applied one sample at a time.
         const bool folds = (fx < 0.0 && fx != trunc(fx) && fx + (double)(sr - 1) > -1.0) ||
@@ -360,7 +374,7 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   RasterParams& P = r->P;
   // coarse grid: bins of c x c tiles, c chosen so that the list storage (bins * nprims entries) stays <= 64 Mi entries
   {
-    uint32_t c = 8;
+    uint32_t c = 4;
     auto bins_for = [&](uint32_t cc) { return (uint64_t)((P.tiles_x + cc - 1) / cc) * ((P.tiles_y + cc - 1) / cc); };
     while (bins_for(c) * (uint64_t)(P.nprims ? P.nprims : 1) > (64ull << 20) && c < 65536) c *= 2;
     P.coarse_tiles = c;
