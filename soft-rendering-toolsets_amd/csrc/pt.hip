@@ -278,7 +278,8 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
-  const size_t lds = (size_t)4 * (F.use_bvh ? F.wave_tlas.size() : 0) * 6 * 64 * sizeof(float);  // 4 waves x Q x 3 rays x 2 fields
+  const size_t nq = F.use_bvh ? F.wave_tlas.size() : 0;
+  const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * 6 * 64 * sizeof(float);  // 4 waves x (Q - 1) x 3 rays x 2 fields
   if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode) {
     pt->wave_mode = pt->kernel_mode;
     int per_cu = 0, cus = 0;

@@ -194,7 +194,7 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
 template <bool STAMP, bool HAS_BLAS>
-__global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+__global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
@@ -222,8 +222,9 @@ __global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams
   //   written by the parent   field 0 = tin.x, field 1 = tin.y      (top-down, before step q)
   //   after step q            field 0 = cur_far_t.x of node q        (tin is dead once read)
   //   after bottom-up step q  field 0 = ret.dist, field 1 = ret.id   (read by the parent)
-  float* wl = lds_f + (size_t)wave * Q * 6 * 64 + lane;
-#define SLOT(q, r, f) wl[(((q) * 3 + (r)) * 2 + (f)) * 64]
+  // The root (q = 0) has no slot: it receives no `times` and nobody reads its result; its cur_far_t.x stays in registers.
+  float* wl = lds_f + (size_t)wave * (Q > 0 ? Q - 1 : 0) * 6 * 64 + lane;
+#define SLOT(q, r, f) wl[((((q) - 1) * 3 + (r)) * 2 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   Counters cnt;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams
       V3 inv[3];
       float tx0[3], ty0[3];
       unsigned long long fl[3] = {0ull, 0ull, 0ull};
+      float farx0[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int r = 0; r < 3; r++) {
         inv[r] = v3(1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams
           const float fx = hb ? (cl ? t2x : t1x) : rb0[r];
           const float fy = hb ? (cl ? t2y : t1y) : rb1[r];
           fl[r] |= (unsigned long long)((hl ? 1u : 0u) | (hr ? 2u : 0u) | (cl ? 4u : 0u) | (hb ? 8u : 0u)) << (4 * q);
-          SLOT(q, r, 0) = fx;
+          if (q != 0) SLOT(q, r, 0) = fx; else farx0[r] = fx;
           if (W.l_ref >= 0) { SLOT(W.l_ref, r, 0) = cl ? cx : fx; SLOT(W.l_ref, r, 1) = cl ? cy : fy; }
           if (W.r_ref >= 0) { SLOT(W.r_ref, r, 0) = cl ? fx : cx; SLOT(W.r_ref, r, 1) = cl ? fy : cy; }
         }
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void pt_wave_kernel(DScene S_in, WaveParams
           Hit ret = no_hit();
           if (f & 3u) {
             ret = rc;
-            const float farx = SLOT(q, r, 0);
+            const float farx = (q != 0) ? SLOT(q, r, 0) : farx0[r];
             if (farx < rc.dist || (!rc.hit && (f & 8u))) {       // student/bvh.inl:216
               if (!left_wins(rc.hit, rc.dist, rs.hit, rs.dist)) ret = rs.hit ? rs : no_hit();
             }
