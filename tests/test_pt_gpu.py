@@ -215,3 +215,36 @@ def test_wave_kernel_equals_general_kernel_and_oracle(srt, name, use_bvh, wh, sp
     mask = part[..., 0] != -1.0
     assert mask.any() and not mask.all() and bits_equal(part[mask], want[mask])
     pt.close()
+
+
+@pytest.mark.parametrize("w,h,depth,spp,tile,world", [
+    (1, 1, 8, 7, (8, 8), 1),        # one pixel
+    (5, 3, 0, 4, (8, 8), 1),        # max_depth 0: only emitted light seen directly
+    (19, 11, 16, 2, (16, 8), 1),    # deepest supported recursion
+    (40, 24, 2, 1, (64, 32), 1),    # tile larger than the image, 1 spp (burst with a single sample)
+    (16, 16, 3, 5, (8, 8), 7),      # more ranks than some ranks have tiles for
+])
+def test_edge_shapes(srt, w, h, depth, spp, tile, world):
+    scene = pt_scene("cbox")
+    want = H.OraclePT(scene, w, h, depth, True).epoch(2**40 + 12345, 2**31 - 3, spp)   # large seed / sample base
+    pt = make_pt(srt, scene, w, h, depth, True)
+    for mode in (2, 4):
+        pt.set_kernel(mode)
+        img = np.full((h, w, 3), -7.0, np.float32)
+        for rank in range(world):
+            pt.set_tiling(tile[0], tile[1], rank, world)
+            pt.render_epoch(2**40 + 12345, 2**31 - 3, spp, out=img)
+        assert bits_equal(img, want), f"mode {mode}"
+    pt.close()
+
+
+def test_zero_samples_and_reuse(srt):
+    """An epoch of zero samples is an image of zeros (do_trace with samples = 0); a context can be re-committed."""
+    pt = make_pt(srt, pt_scene("cbox"), 16, 16, 8, True)
+    assert not pt.render_epoch(1, 0, 0).any()
+    a = pt.render_epoch(1, 0, 3)
+    pt.build_scene(pt_scene("cbox_lambertian"))      # new scene in the same context
+    b = pt.render_epoch(1, 0, 3)
+    want = H.OraclePT(pt_scene("cbox_lambertian"), 16, 16, 8, True).epoch(1, 0, 3)
+    assert bits_equal(b, want) and not bits_equal(a, b)
+    pt.close()
