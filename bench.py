@@ -136,6 +136,21 @@ def raster_bench(device, frames=30, warmup=3):
     }
 
 
+def traffic_bytes(size, spp, world):
+    """HBM bytes per pt_wave_kernel launch from the committed PMC passes (profiles/*_traffic.json, produced by
+    tools/collect_profiles.sh on this workload); None when the run is not the profiled workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        wl = doc.get("workload", {})
+        if (wl.get("size"), wl.get("spp_per_step"), wl.get("n_gpus")) == (size, spp, world):
+            return doc.get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +234,7 @@ def main():
         step(i, False)
     torch.cuda.synchronize()
     pt.ray_count(reset=True)
+    pt.kernel_time(enable=True)      # HIP events around every pt_wave_kernel launch, on the launch stream
     if rank == 0:
         acc.zero_()
 
@@ -234,7 +250,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays, cams = pt.ray_count()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
+    wave_ms_total, wave_launches = pt.kernel_time(enable=False)
+    kernel_ms = wave_ms_total / max(1, wave_launches)          # the dominant kernel alone (agrees with rocprofv3 AverageNs)
+    epoch_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))  # + reduction kernel
     if world > 1:
         cdev = torch.device("cpu") if rehearse else dev
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=cdev)
@@ -277,7 +295,8 @@ def main():
             "mean_radiance": mean_radiance, "image_sha256_16": image_sha,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                "traffic": traffic_bytes(W, spp, world), "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms,
+                "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_launches": wave_launches, "epoch_device_ms": epoch_ms,
                 "algorithmic_bytes_per_ray": bpr,
                 "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
                 "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d)",

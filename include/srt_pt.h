@@ -117,6 +117,12 @@ int srt_pt_set_kernel(srt_pt* pt, int mode);
  * {refill, top-down sweep, leaf objects, combine, finish-direct, shade, terminate, 0}. */
 int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset);
 
+/* Device time of the dominant kernel of render_epoch[_device] (pt_wave_kernel / pt_unit_kernel / pt_epoch_kernel,
+ * whichever the scene selects), measured with HIP events recorded on the launch stream around each launch.
+ * Returns the sum over the launches recorded since the previous call (waits for them), then switches
+ * recording on (enable != 0) or off.  Off by default. */
+int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launches);
+
 /* Rays (scene.hit calls) and camera samples traced by this context since the last reset. */
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);
 

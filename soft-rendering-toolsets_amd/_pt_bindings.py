@@ -36,6 +36,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_accumulate_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint32]
     lib.srt_pt_set_kernel.argtypes = [c_void_p, c_int]
     lib.srt_pt_section_cycles.argtypes = [c_void_p, c_void_p, c_int]
+    lib.srt_pt_kernel_time.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]
     lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -207,6 +208,13 @@ class Pathtracer:
         self._check(self._lib, self._lib.srt_pt_section_cycles(self._ctx, _p(out), int(reset)))
         names = ("refill", "top_down", "leaf_objects", "combine", "finish_direct", "shade", "terminate")
         return dict(zip(names, (int(v) for v in out)))
+
+    def kernel_time(self, enable: bool = True):
+        """(total_ms, launches) of the dominant kernel since the previous call (HIP events on the launch stream,
+        recorded inside the library); then switches recording on/off."""
+        ms, n = ctypes.c_double(), c_uint64()
+        self._check(self._lib, self._lib.srt_pt_kernel_time(self._ctx, int(enable), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def ray_count(self, reset: bool = False):
         """(rays, camera_samples) traced by render_epoch* since the last reset (synchronizes the device)."""

@@ -12,6 +12,8 @@
 // The reference recursion `L = direct + (L_next * atten) * (1/pdf)` is evaluated leaf-first; to round
 // identically the kernel records (direct, atten, 1/pdf) per bounce and folds the records from the last
 // bounce back to the first instead of carrying a running throughput.
+#include <cstdlib>
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -193,11 +195,16 @@ struct srt_pt {
   float* d_samples = nullptr; size_t samples_floats = 0;   // wave kernel: per-unit radiance
   float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
   float* d_running = nullptr; size_t running_floats = 0;   // wave kernel: (sum, count) across launches
+  float* d_cold = nullptr; size_t cold_floats = 0;         // wave kernel: per-lane parked path state
   unsigned long long* d_queue = nullptr;                   // wave kernel: queue head
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1;
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
+  // srt_pt_kernel_time: event pairs recorded around the dominant kernel's launches, on the launch stream
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // pending (recorded, not yet read)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
 };
 
 namespace {
@@ -274,6 +281,22 @@ bool wave_kernel_applies(const srt_pt* pt) {
 
 // One epoch with the wave-uniform persistent kernel: launches of <= 64 samples per pixel, each followed by the
 // ordered per-pixel reduction.
+// Timing brackets for the dominant kernel (srt_pt_kernel_time).
+int time_begin(srt_pt* pt, hipStream_t s) {
+  if (!pt->timing) return SRT_OK;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!pt->spare.empty()) { ev = pt->spare.back(); pt->spare.pop_back(); }
+  else { SRT_HIP(hipEventCreate(&ev.first)); SRT_HIP(hipEventCreate(&ev.second)); }
+  pt->timed.push_back(ev);
+  SRT_HIP(hipEventRecord(ev.first, s));
+  return SRT_OK;
+}
+int time_end(srt_pt* pt, hipStream_t s) {
+  if (!pt->timing) return SRT_OK;
+  SRT_HIP(hipEventRecord(pt->timed.back().second, s));
+  return SRT_OK;
+}
+
 int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
@@ -292,6 +315,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     if (per_cu < 1) return srt::fail(SRT_ERR_UNSUPPORTED, "wave kernel does not fit on a CU (LDS %zu bytes)", lds);
     pt->wave_blocks = per_cu * cus;
     pt->wave_lds = lds;
+    if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_wave_kernel: %d blocks/CU x %d CUs, %zu B LDS per block\n", per_cu, cus, lds);
   }
   const uint32_t chunk = 64;
   const uint32_t nlanes = (uint32_t)pt->wave_blocks * 256;
@@ -299,6 +323,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_records, &pt->records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
+  if ((st = ensure(&pt->d_cold, &pt->cold_floats, (size_t)nlanes * kColdVecs * 4)) != SRT_OK) return st;
   if (!pt->d_queue) {
     SRT_HIP(hipMalloc(&pt->d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
     SRT_HIP(hipMemset(pt->d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
@@ -317,12 +342,15 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
 #define SRT_LAUNCH_WAVE(STAMP_, BLAS_)                                                                                        \
   pt_wave_kernel<STAMP_, BLAS_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
                                                                               DS.lights, DS.light_tris, DS.materials,           \
-                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out)
+                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out, \
+                                                                              reinterpret_cast<uint4*>(pt->d_cold))
       const bool blas = !F.blas_recs.empty();
+      if ((st = time_begin(pt, s)) != SRT_OK) return st;
       if (pt->kernel_mode == 3) { if (blas) SRT_LAUNCH_WAVE(true, true); else SRT_LAUNCH_WAVE(true, false); }
       else { if (blas) SRT_LAUNCH_WAVE(false, true); else SRT_LAUNCH_WAVE(false, false); }
 #undef SRT_LAUNCH_WAVE
       SRT_HIP(hipGetLastError());
+      if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
     pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, pt->d_samples, pt->d_running, first, last, d_tiles_out);
@@ -344,9 +372,11 @@ int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     const uint64_t units = (uint64_t)px * n;
     if (n) {
+      if ((st = time_begin(pt, s)) != SRT_OK) return st;
       pt_unit_kernel<<<dim3((unsigned)((units + 63) / 64)), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base + done, n,
                                                                               (uint32_t)units, pt->d_samples, pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
+      if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
     pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, pt->d_samples, pt->d_running, first, last, d_tiles_out);
@@ -394,7 +424,9 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
-    (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
+    (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue); (void)hipFree(pt->d_cold);
+    for (auto& v : {&pt->timed, &pt->spare})
+      for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(pt->stream);
   }
   delete pt;
@@ -541,9 +573,11 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
       if (st != SRT_OK) return st;
     } else {
       const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
+      if ((st = time_begin(pt, s)) != SRT_OK) return st;
       pt_epoch_kernel<<<dim3(blocks), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base, samples, d_tiles_out,
                                                         pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
+      if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     // camera samples of this epoch: pixels of this rank's tiles that lie inside the image
     uint64_t px = 0;
@@ -622,6 +656,26 @@ int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset) {
   SRT_HIP(hipMemcpy(h, pt->d_queue + 1, sizeof h, hipMemcpyDeviceToHost));
   for (int i = 0; i < ST_COUNT_; i++) out[i] = h[i];
   if (reset) SRT_HIP(hipMemset(pt->d_queue + 1, 0, sizeof h));
+  return SRT_OK;
+}
+
+int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launches) {
+  int st = need_device(pt, "srt_pt_kernel_time");
+  if (st != SRT_OK) return st;
+  double sum = 0.0;
+  uint64_t n = 0;
+  for (auto& ev : pt->timed) {
+    SRT_HIP(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    SRT_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+    sum += ms;
+    n++;
+    pt->spare.push_back(ev);
+  }
+  pt->timed.clear();
+  pt->timing = enable != 0;
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = n;
   return SRT_OK;
 }
 

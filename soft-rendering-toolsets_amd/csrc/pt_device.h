@@ -188,15 +188,17 @@ SRT_DEV double pow5d(float x) { const double d = (double)x, d2 = d * d, d4 = d2 
 SRT_DEV bool box_hit(const Node& nd, const Ray& ray, float& tx, float& ty) {
   const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
   const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;
-  float tmin = ((sx ? nd.mx[0] : nd.mn[0]) - ray.o.x) * ix;
-  float tmax = ((sx ? nd.mn[0] : nd.mx[0]) - ray.o.x) * ix;
-  const float tymin = ((sy ? nd.mx[1] : nd.mn[1]) - ray.o.y) * iy;
-  const float tymax = ((sy ? nd.mn[1] : nd.mx[1]) - ray.o.y) * iy;
+  // bounds as values before the selects (an lvalue select would become a load from a selected address)
+  const float mn0 = nd.mn[0], mn1 = nd.mn[1], mn2 = nd.mn[2], mx0 = nd.mx[0], mx1 = nd.mx[1], mx2 = nd.mx[2];
+  float tmin = ((sx ? mx0 : mn0) - ray.o.x) * ix;
+  float tmax = ((sx ? mn0 : mx0) - ray.o.x) * ix;
+  const float tymin = ((sy ? mx1 : mn1) - ray.o.y) * iy;
+  const float tymax = ((sy ? mn1 : mx1) - ray.o.y) * iy;
   if ((tmin > tymax) || (tymin > tmax)) return false;
   if (tymin > tmin) tmin = tymin;
   if (tymax < tmax) tmax = tymax;
-  const float tzmin = ((sz ? nd.mx[2] : nd.mn[2]) - ray.o.z) * iz;
-  const float tzmax = ((sz ? nd.mn[2] : nd.mx[2]) - ray.o.z) * iz;
+  const float tzmin = ((sz ? mx2 : mn2) - ray.o.z) * iz;
+  const float tzmax = ((sz ? mn2 : mx2) - ray.o.z) * iz;
   if ((tmin > tzmax) || (tzmin > tmax)) return false;
   if (tzmin > tmin) tmin = tzmin;
   if (tzmax < tmax) tmax = tzmax;

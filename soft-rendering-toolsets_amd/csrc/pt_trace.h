@@ -137,15 +137,18 @@ SRT_DEV void fold(Hit& best, bool hit, float dist, uint32_t obj, uint32_t tri) {
 // BBox::hit on a record's child box with the reciprocal direction hoisted, straight-line form.
 SRT_DEV bool box_hit_rec(const float* __restrict__ bx, V3 o, V3 inv, float& tx, float& ty) {
   const bool sx = inv.x < 0, sy = inv.y < 0, sz = inv.z < 0;
-  float tmin = ((sx ? bx[3] : bx[0]) - o.x) * inv.x;
-  float tmax = ((sx ? bx[0] : bx[3]) - o.x) * inv.x;
-  const float tymin = ((sy ? bx[4] : bx[1]) - o.y) * inv.y;
-  const float tymax = ((sy ? bx[1] : bx[4]) - o.y) * inv.y;
+  // the six bounds are read into values first: `c ? bx[3] : bx[0]` on the memory operands is an lvalue select,
+  // i.e. one per-lane vector load from a selected address instead of two wave-uniform scalar loads
+  const float b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5];
+  float tmin = ((sx ? b3 : b0) - o.x) * inv.x;
+  float tmax = ((sx ? b0 : b3) - o.x) * inv.x;
+  const float tymin = ((sy ? b4 : b1) - o.y) * inv.y;
+  const float tymax = ((sy ? b1 : b4) - o.y) * inv.y;
   const bool miss_y = (tmin > tymax) || (tymin > tmax);
   tmin = (tymin > tmin) ? tymin : tmin;
   tmax = (tymax < tmax) ? tymax : tmax;
-  const float tzmin = ((sz ? bx[5] : bx[2]) - o.z) * inv.z;
-  const float tzmax = ((sz ? bx[2] : bx[5]) - o.z) * inv.z;
+  const float tzmin = ((sz ? b5 : b2) - o.z) * inv.z;
+  const float tzmax = ((sz ? b2 : b5) - o.z) * inv.z;
   const bool miss_z = (tmin > tzmax) || (tzmin > tmax);
   tmin = (tzmin > tmin) ? tzmin : tmin;
   tmax = (tzmax < tmax) ? tzmax : tmax;
@@ -462,16 +465,17 @@ SRT_DEV float light_pdf(const DScene& S, V3 from, V3 dir, Counters& cnt) {
 }
 
 // Camera::generate_ray (student/camera.cpp:7-34); screen_h/screen_w come from the host (tanf).
-SRT_DEV Ray camera_ray(const DScene& S, float sx, float sy) {
-  const float sh = S.cam.screen_h, sw = S.cam.screen_w;
+SRT_DEV Ray camera_ray(const Camera& cam, float sx, float sy) {
+  const float sh = cam.screen_h, sw = cam.screen_w;
   Ray r;
   r.o = v3(0, 0, 0);
   r.d = v3(sx * sw - 0.5f * sw, sy * sh - 0.5f * sh, -1.0f);
   r.b0 = 0.0f;
   r.b1 = __uint_as_float(0x7f800000u);
-  ray_transform(r, S.cam.iview);
+  ray_transform(r, cam.iview);
   return r;
 }
+SRT_DEV Ray camera_ray(const DScene& S, float sx, float sy) { return camera_ray(S.cam, sx, sy); }
 
 // `trace(ray).first` of a depth-0 ray: emitted radiance of whatever it hits, else zero.
 template <bool COUNT>

@@ -44,6 +44,7 @@ constexpr uint32_t kWaveMaxObjects = 16;
 constexpr uint32_t kChunk = 512;          // units (sample triples) a wave reserves per queue atomic
 constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
+constexpr int kColdVecs = 5;
 constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
 
 struct WaveParams {
@@ -60,6 +61,26 @@ struct WaveParams {
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
   unsigned long long* stamps;       // STAMP build only: per-section cycle sums
 };
+
+// Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
+// (integer-division reciprocals, int->float conversions, matrix * constant products) can no longer be hoisted out
+// of the persistent loop into VGPRs, where it would sit for the whole kernel or be spilled to scratch.
+SRT_DEV uint32_t opq(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
+SRT_DEV float opq(float v) { asm volatile("" : "+s"(v)); return v; }
+SRT_DEV uint64_t opq(uint64_t v) { asm volatile("" : "+s"(v)); return v; }
+SRT_DEV TileMap opq(const TileMap& t) {
+  return TileMap{opq(t.tile_w), opq(t.tile_h), opq(t.tiles_x), opq(t.tiles_y), opq(t.rank), opq(t.world), opq(t.local_tiles)};
+}
+SRT_DEV Camera opq(const Camera& c) {
+  Camera o;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) o.iview.c[i][j] = opq(c.iview.c[i][j]);
+  o.vert_fov = c.vert_fov; o.aspect_ratio = c.aspect_ratio;
+  o.screen_h = opq(c.screen_h); o.screen_w = opq(c.screen_w);
+  return o;
+}
 
 // pixel of local pixel index p (tile-major, 8x8 blocks inside a tile; same order as pt_epoch_kernel)
 SRT_DEV void unit_pixel(const TileMap& T, uint32_t p, uint32_t& x, uint32_t& y) {
@@ -96,15 +117,18 @@ SRT_DEV V3 mat_point_uniform(const Mat4& m, V3 v) {
 // straight-line form: the two early-outs become one verdict, `times` is narrowed only on a hit.
 SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, float& ty) {
   const bool sx = inv.x < 0, sy = inv.y < 0, sz = inv.z < 0;
-  float tmin = ((sx ? bx[3] : bx[0]) - o.x) * inv.x;
-  float tmax = ((sx ? bx[0] : bx[3]) - o.x) * inv.x;
-  const float tymin = ((sy ? bx[4] : bx[1]) - o.y) * inv.y;
-  const float tymax = ((sy ? bx[1] : bx[4]) - o.y) * inv.y;
+  // the six bounds are read into values first: `c ? bx[3] : bx[0]` on the memory operands is an lvalue select,
+  // i.e. one per-lane vector load from a selected address instead of two wave-uniform scalar loads
+  const float b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5];
+  float tmin = ((sx ? b3 : b0) - o.x) * inv.x;
+  float tmax = ((sx ? b0 : b3) - o.x) * inv.x;
+  const float tymin = ((sy ? b4 : b1) - o.y) * inv.y;
+  const float tymax = ((sy ? b1 : b4) - o.y) * inv.y;
   const bool miss_y = (tmin > tymax) || (tymin > tmax);
   tmin = (tymin > tmin) ? tymin : tmin;
   tmax = (tymax < tmax) ? tymax : tmax;
-  const float tzmin = ((sz ? bx[5] : bx[2]) - o.z) * inv.z;
-  const float tzmax = ((sz ? bx[2] : bx[5]) - o.z) * inv.z;
+  const float tzmin = ((sz ? b5 : b2) - o.z) * inv.z;
+  const float tzmax = ((sz ? b2 : b5) - o.z) * inv.z;
   const bool miss_z = (tmin > tzmax) || (tzmin > tmax);
   tmin = (tzmin > tmin) ? tzmin : tmin;
   tmax = (tzmax < tmax) ? tzmax : tmax;
@@ -199,7 +223,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
                                                       const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
-                                                      float* __restrict__ a_records, float* __restrict__ a_samples) {
+                                                      float* __restrict__ a_records, float* __restrict__ a_samples, uint4* __restrict__ a_cold) {
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
@@ -257,7 +281,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
     const unsigned long long need = __ballot(!alive);
     if (need != 0ull && !(queue_empty && chunk_next == chunk_end)) {
       const uint32_t want = (uint32_t)__popcll(need);
-      const uint32_t my_rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+      const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
       uint32_t given = 0, my_unit = kMissTri;
       while (given < want) {
         if (chunk_next == chunk_end) {
@@ -277,25 +301,29 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
       }
       if (my_unit != kMissTri) {
         uint32_t x, y;
-        unit_pixel(P.T, my_unit / P.groups, x, y);
-        if (x < S.w && y < S.h) {                       // padding pixels of edge tiles are never read
+        const uint32_t groups = opq(P.groups), nsamples = opq(P.samples), img_w = opq(S.w), img_h = opq(S.h);
+        unit_pixel(opq(P.T), my_unit / groups, x, y);
+        if (x < img_w && y < img_h) {                   // padding pixels of edge tiles are never read
           alive = true;
           burst = true;
           px = x; py = y;
-          pixel_slot = my_unit / P.groups;
-          s_first = (my_unit % P.groups) * kBurst;
-          s_count = P.samples - s_first < kBurst ? P.samples - s_first : kBurst;
+          pixel_slot = my_unit / groups;
+          s_first = (my_unit % groups) * kBurst;
+          s_count = nsamples - s_first < kBurst ? nsamples - s_first : kBurst;
           s_cur = s_first;
           level = 0;
           depth = S.max_depth;
           // camera rays of the unit's samples (trace_pixel, student/pathtracer.cpp:26-31); absent samples repeat the first
+          const Camera cam_c = opq(S.cam);
+          const uint64_t seed = opq(P.seed);
+          const uint32_t sample_base = opq(P.sample_base);
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             const uint32_t sj = s_first + ((uint32_t)j < s_count ? (uint32_t)j : 0u);
-            rng.key(P.seed, y * S.w + x, P.sample_base + sj);
+            rng.key(seed, y * img_w + x, sample_base + sj);
             const float jx = rng.unit() * 1.0f;
             const float jy = rng.unit() * 1.0f;
-            const Ray cam = camera_ray(S, ((float)x + jx) / (float)S.w, ((float)y + jy) / (float)S.h);
+            const Ray cam = camera_ray(cam_c, ((float)x + jx) / (float)img_w, ((float)y + jy) / (float)img_h);
             org = cam.o;                                // the same for every camera ray (iview * origin)
             d[j] = cam.d; cb0 = cam.b0; cb1 = cam.b1;
           }
@@ -492,10 +520,11 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
         ray.o = org; ray.d = d[2]; ray.b0 = cb0; ray.b1 = cb1;
         if (level == 0) {
           // a camera ray: regenerate it (and the RNG position after its two jitter draws) from the sample index
-          rng.key(P.seed, py * S.w + px, P.sample_base + s_cur);
+          const uint32_t img_w = opq(S.w), img_h = opq(S.h);
+          rng.key(opq(P.seed), py * img_w + px, opq(P.sample_base) + s_cur);
           const float jx = rng.unit() * 1.0f;
           const float jy = rng.unit() * 1.0f;
-          ray = camera_ray(S, ((float)px + jx) / (float)S.w, ((float)py + jy) / (float)S.h);
+          ray = camera_ray(opq(S.cam), ((float)px + jx) / (float)img_w, ((float)py + jy) / (float)img_h);
         }
         burst = false;
         Surface sf = surface_of(S, ch, ray);

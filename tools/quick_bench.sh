@@ -1,0 +1,6 @@
+#!/bin/bash
+# short PT-only bench line: Mrays/s, ms/step, image hash, dominant-kernel ms
+python bench.py --steps ${1:-8} --no-cpu-baseline --no-raster 2>&1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(round(d['value'], 1), 'Mrays/s', round(d['ms_per_step'], 2), 'ms/step', d['image_sha256_16'], 'kernel', round(d['roofline']['kernel_ms'], 2), 'ms')"
