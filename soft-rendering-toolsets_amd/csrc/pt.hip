@@ -195,7 +195,6 @@ struct srt_pt {
   float* d_samples = nullptr; size_t samples_floats = 0;   // wave kernel: per-unit radiance
   float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
   float* d_running = nullptr; size_t running_floats = 0;   // wave kernel: (sum, count) across launches
-  float* d_cold = nullptr; size_t cold_floats = 0;         // wave kernel: per-lane parked path state
   unsigned long long* d_queue = nullptr;                   // wave kernel: queue head
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1;
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
@@ -323,7 +322,6 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_records, &pt->records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
-  if ((st = ensure(&pt->d_cold, &pt->cold_floats, (size_t)nlanes * kColdVecs * 4)) != SRT_OK) return st;
   if (!pt->d_queue) {
     SRT_HIP(hipMalloc(&pt->d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
     SRT_HIP(hipMemset(pt->d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
@@ -342,8 +340,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
 #define SRT_LAUNCH_WAVE(STAMP_, BLAS_)                                                                                        \
   pt_wave_kernel<STAMP_, BLAS_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
                                                                               DS.lights, DS.light_tris, DS.materials,           \
-                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out, \
-                                                                              reinterpret_cast<uint4*>(pt->d_cold))
+                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out)
       const bool blas = !F.blas_recs.empty();
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
       if (pt->kernel_mode == 3) { if (blas) SRT_LAUNCH_WAVE(true, true); else SRT_LAUNCH_WAVE(true, false); }
@@ -424,7 +421,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
-    (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue); (void)hipFree(pt->d_cold);
+    (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
     for (auto& v : {&pt->timed, &pt->spare})
       for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(pt->stream);

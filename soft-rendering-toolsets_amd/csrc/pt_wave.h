@@ -44,7 +44,6 @@ constexpr uint32_t kWaveMaxObjects = 16;
 constexpr uint32_t kChunk = 512;          // units (sample triples) a wave reserves per queue atomic
 constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
-constexpr int kColdVecs = 5;
 constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
 
 struct WaveParams {
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
                                                       const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
-                                                      float* __restrict__ a_records, float* __restrict__ a_samples, uint4* __restrict__ a_cold) {
+                                                      float* __restrict__ a_records, float* __restrict__ a_samples) {
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
