@@ -57,13 +57,18 @@ def cpu_cores():
     return min(n, int(os.environ.get("SRT_BENCH_CPU_THREADS", "16")))
 
 
-def pt_cpu_baseline(scene, w, h, depth, seed, budget_s=15.0):
-    """The oracle (validated CPU restatement of the reference) on the host cores, same scene / size /
-    seed, reduced spp: rows are split over `cores` threads (ctypes releases the GIL)."""
+def pt_cpu_baseline(scene, w, h, depth, seed, pt, budget_s=15.0):
+    """The CPU path on the host cores, same scene / size / seed, reduced spp, rows split over `cores` threads
+    (ctypes releases the GIL), the way the reference's thread pool spreads its epochs.
+    kind "reference": the reference's own PT::Pathtracer::trace_pixel compiled from /root/reference into
+    oracle/_ref/libref_pt.so (prebuilt, travels with the tree); its image must equal the HIP image of the same
+    samples bit for bit, and its ray count is the HIP path's count for those samples.
+    kind "port": oracle/pt_oracle.c (the validated restatement) when oracle/_ref is absent."""
     import _harness as H
 
     cores = cpu_cores()
-    o = H.OraclePT(scene, w, h, depth, True, math_mode=1)
+    use_ref = H.ref_pt_lib() is not None
+    o = H.RefPT(scene, w, h, depth, True) if use_ref else H.OraclePT(scene, w, h, depth, True, math_mode=1)
     img = np.zeros((h, w, 3), np.float32)
 
     def run(spp, rows):
@@ -71,7 +76,10 @@ def pt_cpu_baseline(scene, w, h, depth, seed, budget_s=15.0):
         bounds = np.linspace(0, rows, cores + 1).astype(int)
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(lambda k: o.epoch(seed, 0, spp, int(bounds[k]), int(bounds[k + 1]), img, cnts[k]), range(cores)))
+            if use_ref:
+                list(ex.map(lambda k: o.epoch_rows(seed, 0, spp, int(bounds[k]), int(bounds[k + 1]), img), range(cores)))
+            else:
+                list(ex.map(lambda k: o.epoch(seed, 0, spp, int(bounds[k]), int(bounds[k + 1]), img, cnts[k]), range(cores)))
         dt = time.perf_counter() - t0
         return dt, int(sum(int(c[0]) for c in cnts))
 
@@ -79,9 +87,21 @@ def pt_cpu_baseline(scene, w, h, depth, seed, budget_s=15.0):
     per_spp_full = dt * 8.0
     spp = int(max(1, min(64, budget_s / max(per_spp_full, 1e-3))))
     dt, rays = run(spp, h)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/pt_oracle.c, same scene/seed, {w}x{h} at {spp} spp ({rays / 1e6:.1f} M rays in {dt:.1f} s), "
-                      f"{w * h * spp / dt / 1e6:.2f} M camera samples/s"}
+    out = {"unit": "Mrays/s", "cores": cores, "kind": "reference" if use_ref else "port"}
+    if use_ref:
+        # the HIP path on exactly these samples: same image bits, and its scene.hit count is the reference's
+        pt.set_tiling(32, 32, 0, 1)
+        pt.ray_count(reset=True)
+        gpu = pt.render_epoch(seed, 0, spp)
+        rays, _ = pt.ray_count(reset=True)
+        out["image_equals_hip_bit_for_bit"] = bool(np.array_equal(gpu.view(np.uint32), img.view(np.uint32)))
+        what = "oracle/_ref/libref_pt.so = the reference's PT::Pathtracer::trace_pixel (clang++ -O2) with the seeded SRT-RNG"
+    else:
+        what = "oracle/pt_oracle.c"
+    out["value"] = rays / dt / 1e6
+    out["sample"] = (f"{what}, same scene/seed, {w}x{h} at {spp} spp ({rays / 1e6:.1f} M rays in {dt:.1f} s), "
+                     f"{w * h * spp / dt / 1e6:.2f} M camera samples/s")
+    return out
 
 
 def raster_bench(device, frames=30, warmup=3):
@@ -116,9 +136,15 @@ def raster_bench(device, frames=30, warmup=3):
     wall = time.perf_counter() - t0
     ms = e0.elapsed_time(e1) / frames
     alg_bytes = 40.0 * st.bin_entries + 4.0 * w * h          # SURVEY.md §8(d) rasterizer formula (fused resolve)
+    o_rgba, _, counts = H.oracle_raster_frame(g["prims"], w, h, sr)       # fragment count of the frame (checker)
+    use_ref = os.path.exists(os.path.join(H.ORACLE_DIR, "_ref", "libref_raster.so"))
     t = time.perf_counter()
-    o_rgba, _, counts = H.oracle_raster_frame(g["prims"], w, h, sr)
+    if use_ref:   # the reference's SoftwareRendererImp (clear + rasterize_* + resolve) on the same primitive stream
+        r_rgba, _ = H.ref_raster_prims(g["prims"], w, h, sr)
+    else:
+        r_rgba, _, _ = H.oracle_raster_frame(g["prims"], w, h, sr)
     cpu_s = time.perf_counter() - t
+    ok = ok and bool(np.array_equal(r_rgba, out))
     ren.close()
     return {
         "metric": "Mfrags/s triangle fill", "value": st.fragments / (ms * 1e-3) / 1e6, "unit": "Mfrags/s",
@@ -131,8 +157,11 @@ def raster_bench(device, frames=30, warmup=3):
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "note": "tile kernel is LDS/VALU bound: the 256 MiB supersample buffer never leaves the CUs"},
-        "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1, "kind": "port",
-                         "sample": f"oracle/raster_oracle.c, one full frame of the same stream in {cpu_s * 1e3:.0f} ms"},
+        "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1,
+                         "kind": "reference" if use_ref else "port",
+                         "sample": (("oracle/_ref/libref_raster.so = the reference's SoftwareRendererImp (g++ -O2)" if use_ref
+                                     else "oracle/raster_oracle.c")
+                                    + f", one full frame of the same stream in {cpu_s * 1e3:.0f} ms, output equals the HIP frame")},
     }
 
 
@@ -303,7 +332,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed)
+            out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt)
         if not args.no_raster and world == 1:
             out["raster"] = raster_bench(local_rank)
         print(json.dumps(out), flush=True)

@@ -247,6 +247,30 @@ int ref_pt_epoch(void* h, uint64_t seed, uint32_t sample_base, uint32_t samples,
   return 0;
 }
 
+// The same for rows [row0, row1) only (img_out still addresses the whole image): lets a caller spread one epoch
+// over host threads the way the reference's thread pool spreads epochs.  trace_pixel only reads the scene and
+// the RNG state is thread_local, so concurrent calls on one handle are safe.
+int ref_pt_epoch_rows(void* h, uint64_t seed, uint32_t sample_base, uint32_t samples, uint32_t row0, uint32_t row1,
+                      float* img_out) {
+  RefPT* r = (RefPT*)h;
+  const size_t w = r->pt->out_w, hh = r->pt->out_h;
+  for (size_t j = row0; j < row1 && j < hh; j++) {
+    for (size_t i = 0; i < w; i++) {
+      Spectrum acc;
+      size_t sampled = 0;
+      for (uint32_t s = 0; s < samples; s++) {
+        g_rng.key(seed, (uint32_t)(j * w + i), sample_base + s);
+        Spectrum p = r->pt->trace_pixel(i, j);
+        if (p.valid()) { acc += p; sampled++; }
+      }
+      if (sampled > 0) acc *= (1.0f / sampled);
+      float* o = img_out + 3 * (j * w + i);
+      o[0] = acc.r; o[1] = acc.g; o[2] = acc.b;
+    }
+  }
+  return 0;
+}
+
 // scene.hit for explicit rays: hit flag, distance, position, normal, material (Trace, rays/trace.h).
 int ref_pt_hit(void* h, const float* org, const float* dir, const float* bounds, size_t n, float* out8) {
   RefPT* r = (RefPT*)h;

@@ -168,6 +168,10 @@ class RefPT(_SceneFeeder):
         assert self.lib.ref_pt_epoch(self.h_, ctypes.c_uint64(seed), sample_base, samples, P(img)) == 0
         return img
 
+    def epoch_rows(self, seed, sample_base, samples, row0, row1, img):
+        """Rows [row0, row1) of one epoch into img (h, w, 3); safe to call from several threads at once."""
+        assert self.lib.ref_pt_epoch_rows(self.h_, ctypes.c_uint64(seed), sample_base, samples, row0, row1, P(img)) == 0
+
     def hit(self, org, dirs, bounds):
         org, dirs, bounds = _f32(org), _f32(dirs), _f32(bounds)
         out = np.zeros((len(org), 9), np.float32)
