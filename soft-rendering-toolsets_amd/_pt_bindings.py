@@ -200,7 +200,8 @@ class Pathtracer:
         self._check(self._lib, self._lib.srt_pt_accumulate_device(self._ctx, c_void_p(stream), c_void_p(d_acc), c_void_p(d_epoch), nfloats, k))
 
     def set_kernel(self, mode: int) -> None:
-        """0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel."""
+        """0 auto, 1 lane per pixel, 2 wave-uniform sweeps, 3 the same with section stamps, 4 lane per sample,
+        5 persistent waves with the flattened per-lane walk (include/srt_pt.h)."""
         self._check(self._lib, self._lib.srt_pt_set_kernel(self._ctx, int(mode)))
 
     def section_cycles(self, reset: bool = False) -> dict:

@@ -120,16 +120,28 @@ __global__ __launch_bounds__(64) void pt_samples_kernel(DScene S, uint64_t seed,
   }
 }
 
+// FLAT: the query goes through flat_trace3 (pt_flat.h) in batch slot i % 3 instead of the nested scene_hit.
+template <bool FLAT>
 __global__ void pt_hit_kernel(DScene S, const float* __restrict__ org, const float* __restrict__ dir,
                               const float* __restrict__ bounds, uint32_t n, float* __restrict__ out9) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;                     // every lane stays in the kernel: flat_trace3 is a wave-wide loop
+  const uint32_t j = live ? i : 0;
   Ray r;
-  r.o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
-  r.d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-  r.b0 = bounds[2 * i]; r.b1 = bounds[2 * i + 1];
+  r.o = v3(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
+  r.d = v3(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
+  r.b0 = bounds[2 * j]; r.b1 = bounds[2 * j + 1];
   Counters cnt;
-  const Hit h = scene_hit<false>(S, r, cnt);
+  Hit h;
+  if (FLAT) {
+    const uint32_t slot = i % 3u;
+    Hit res[3];
+    flat_trace3(S, r.o, r.d, r.d, r.d, r.b0, r.b1, live && slot == 0, live && slot == 1, live && slot == 2, res[0], res[1], res[2]);
+    h = slot == 0 ? res[0] : (slot == 1 ? res[1] : res[2]);
+  } else {
+    h = scene_hit<false>(S, r, cnt);
+  }
+  if (!live) return;
   float* o = out9 + 9 * i;
   for (int k = 0; k < 9; k++) o[k] = 0.0f;
   if (h.hit) {
@@ -196,7 +208,7 @@ struct srt_pt {
   float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
   float* d_running = nullptr; size_t running_floats = 0;   // wave kernel: (sum, count) across launches
   unsigned long long* d_queue = nullptr;                   // wave kernel: queue head
-  int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1;
+  int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
@@ -268,15 +280,24 @@ int ensure(T** buf, size_t* have, size_t need) {
   return SRT_OK;
 }
 
-bool wave_kernel_applies(const srt_pt* pt) {
+// Which traversal the persistent wave kernel would use for this scene and kernel mode: 0 wave-uniform sweeps,
+// 1 sweeps + per-lane walk of each BVH<Triangle>, 2 flattened per-lane walk (pt_flat.h); -1: not the wave kernel.
+int wave_trav(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
-  if (pt->kernel_mode == 1 || pt->kernel_mode == 4) return false;
-  const bool fits = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
-  // auto mode: meshes with a real BVH<Triangle> make the lanes of a lockstep batch wait for the deepest walk;
-  // the per-lane kernel handles those scenes better
-  if (pt->kernel_mode == 0 && !F.blas_recs.empty()) return false;
-  return fits;
+  const int m = pt->kernel_mode;
+  if (m == 1 || m == 4) return -1;
+  const bool blas = !F.blas_recs.empty();
+  const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
+  bool flat_fits = F.objects.size() >= 1 && F.objects.size() <= 31 && F.tris.size() < (1u << 27);   // pack_ret: 5 + 27 bits
+  for (const WaveInterior& w : F.wave_tlas)
+    if ((w.l_ref < 0 && w.l_cnt > kFlatMaxLeafObjects) || (w.r_ref < 0 && w.r_cnt > kFlatMaxLeafObjects)) flat_fits = false;
+  if (m == 2 || m == 3) return sweeps_fit ? (blas ? 1 : 0) : -1;
+  if (m == 5) return flat_fits ? 2 : -1;
+  // auto: sweeps for small scenes of single-leaf meshes; meshes with a real BVH<Triangle> go to the flattened walk
+  if (sweeps_fit && !blas) return 0;
+  return flat_fits ? 2 : -1;
 }
+bool wave_kernel_applies(const srt_pt* pt) { return wave_trav(pt) >= 0; }
 
 // One epoch with the wave-uniform persistent kernel: launches of <= 64 samples per pixel, each followed by the
 // ordered per-pixel reduction.
@@ -300,14 +321,16 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
-  const size_t nq = F.use_bvh ? F.wave_tlas.size() : 0;
+  const int trav = wave_trav(pt);
+  const bool stamp = pt->kernel_mode == 3;
+  const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
   const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * 6 * 64 * sizeof(float);  // 4 waves x (Q - 1) x 3 rays x 2 fields
-  if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode) {
+  const void* kern = stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0> : trav == 1 ? (const void*)pt_wave_kernel<true, 1> : (const void*)pt_wave_kernel<true, 2>)
+                           : (trav == 0 ? (const void*)pt_wave_kernel<false, 0> : trav == 1 ? (const void*)pt_wave_kernel<false, 1> : (const void*)pt_wave_kernel<false, 2>);
+  if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode || pt->wave_kern != kern) {
     pt->wave_mode = pt->kernel_mode;
+    pt->wave_kern = kern;
     int per_cu = 0, cus = 0;
-    const bool blas = !F.blas_recs.empty();
-    const void* kern = pt->kernel_mode == 3 ? (blas ? (const void*)pt_wave_kernel<true, true> : (const void*)pt_wave_kernel<true, false>)
-                                            : (blas ? (const void*)pt_wave_kernel<false, true> : (const void*)pt_wave_kernel<false, false>);
     SRT_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
@@ -337,14 +360,13 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
-#define SRT_LAUNCH_WAVE(STAMP_, BLAS_)                                                                                        \
-  pt_wave_kernel<STAMP_, BLAS_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
+#define SRT_LAUNCH_WAVE(STAMP_, TRAV_)                                                                                        \
+  pt_wave_kernel<STAMP_, TRAV_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
                                                                               DS.lights, DS.light_tris, DS.materials,           \
                                                                               DS.wave_tlas, DS.blas_recs, P.records, P.sample_out)
-      const bool blas = !F.blas_recs.empty();
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
-      if (pt->kernel_mode == 3) { if (blas) SRT_LAUNCH_WAVE(true, true); else SRT_LAUNCH_WAVE(true, false); }
-      else { if (blas) SRT_LAUNCH_WAVE(false, true); else SRT_LAUNCH_WAVE(false, false); }
+      if (stamp) { if (trav == 0) SRT_LAUNCH_WAVE(true, 0); else if (trav == 1) SRT_LAUNCH_WAVE(true, 1); else SRT_LAUNCH_WAVE(true, 2); }
+      else { if (trav == 0) SRT_LAUNCH_WAVE(false, 0); else if (trav == 1) SRT_LAUNCH_WAVE(false, 1); else SRT_LAUNCH_WAVE(false, 2); }
 #undef SRT_LAUNCH_WAVE
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
@@ -543,8 +565,8 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
 
 int srt_pt_set_kernel(srt_pt* pt, int mode) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_kernel: NULL context");
-  if (mode < 0 || mode > 4)
-    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped) or 4 (per-lane, lane per sample)");
+  if (mode < 0 || mode > 5)
+    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped), 4 (per-lane, lane per sample) or 5 (persistent waves, flattened per-lane walk)");
   pt->kernel_mode = mode;
   return SRT_OK;
 }
@@ -562,6 +584,8 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
     if ((pt->kernel_mode == 2 || pt->kernel_mode == 3) && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "wave-uniform kernel needs 1..%u objects (scene has %zu)", kWaveMaxObjects,
                        pt->built.flat.objects.size());
+    if (pt->kernel_mode == 5 && !wave_kernel_applies(pt))
+      return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened-walk kernel needs 1..31 objects (scene has %zu)", pt->built.flat.objects.size());
     if (wave_kernel_applies(pt)) {
       st = render_epoch_wave(pt, s, seed, sample_base, samples, d_tiles_out);
       if (st != SRT_OK) return st;
@@ -732,7 +756,12 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
   SRT_HIP(hipMemcpyAsync(ddir, dirs, n * 12, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(db, bounds, n * 8, hipMemcpyHostToDevice, pt->stream));
   DScene S = device_scene(pt);
-  pt_hit_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, pt->stream>>>(S, dorg, ddir, db, (uint32_t)n, dout);
+  if (pt->kernel_mode == 5) {
+    if (wave_trav(pt) != 2) return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened walk needs 1..31 objects");
+    pt_hit_kernel<true><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, pt->stream>>>(S, dorg, ddir, db, (uint32_t)n, dout);
+  } else {
+    pt_hit_kernel<false><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, pt->stream>>>(S, dorg, ddir, db, (uint32_t)n, dout);
+  }
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out9, dout, n * 36, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));

@@ -5,6 +5,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 
 namespace srt {

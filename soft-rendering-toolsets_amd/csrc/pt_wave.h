@@ -37,6 +37,7 @@
 #define SRT_PT_WAVE_H
 
 #include "pt_trace.h"
+#include "pt_flat.h"
 
 namespace srt {
 
@@ -216,7 +217,7 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // STAMP = true is a diagnostic build: s_memtime deltas of the loop's sections are summed per wave and added to
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
-template <bool STAMP, bool HAS_BLAS>
+template <bool STAMP, int TRAV>
 __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
@@ -342,13 +343,18 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
     const float rb0[3] = {cb0, cb0, cb0};
     const float rb1[3] = {cb1, cb1, cb1};
     Hit res[3];
-    if (Q == 0) {
+    if (TRAV == 2) {
+      // general scenes: one flattened per-lane walk over both tree levels for the slots that carry a ray
+      const bool a0 = alive && (burst || actA), a1 = alive && (burst ? actA : actB), a2 = alive && (burst ? actB : true);
+      flat_trace3(S, org, d[0], d[1], d[2], cb0, cb1, a0, a1, a2, res[0], res[1], res[2]);
+      SECTION_END(ST_LEAVES)
+    } else if (Q == 0) {
       // List<Object>::hit, or a BVH<Object> whose root is a leaf: ordered fold over every object
 #pragma unroll
       for (int r = 0; r < 3; r++) res[r] = no_hit();
       for (uint32_t k = 0; k < nobj; k++) {
         bool h[3]; float dd[3]; uint32_t tt[3];
-        object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+        object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
         for (int r = 0; r < 3; r++) fold(res[r], h[r], dd[r], k, tt[r]);
       }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
           const uint32_t first = (uint32_t)~W.l_ref;
           for (uint32_t k = first; k < first + W.l_cnt; k++) {
             bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
             for (int r = 0; r < 3; r++) fold(L[r], h[r], dd[r], k, tt[r]);
           }
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
           const uint32_t first = (uint32_t)~W.r_ref;
           for (uint32_t k = first; k < first + W.r_cnt; k++) {
             bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3<HAS_BLAS>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
             for (int r = 0; r < 3; r++) fold(R[r], h[r], dd[r], k, tt[r]);
           }

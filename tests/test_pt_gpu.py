@@ -194,20 +194,21 @@ def test_full_size_properties(srt):
     ("cbox_refract", True, (32, 32), 3, 8),
 ])
 def test_wave_kernel_equals_general_kernel_and_oracle(srt, name, use_bvh, wh, spp, depth):
-    """The wave-uniform persistent kernel (mode 2) and the general per-lane kernel (mode 1) are two
-    independent device implementations; both must reproduce the oracle's epoch image bit for bit."""
+    """The wave-uniform persistent kernel (mode 2), the same kernel with the flattened per-lane walk (mode 5) and
+    the general per-lane kernels (modes 1, 4) are independent device implementations of scene.hit; all must
+    reproduce the oracle's epoch image bit for bit."""
     scene = pt_scene(name)
     w, h = wh
     want = H.OraclePT(scene, w, h, depth, use_bvh).epoch(5, 9, spp)
     pt = make_pt(srt, scene, w, h, depth, use_bvh)
     rays = []
-    for mode in (1, 2, 4):
+    for mode in (1, 2, 4, 5):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         img = pt.render_epoch(5, 9, spp)
         assert bits_equal(img, want), f"kernel mode {mode} differs from the oracle"
         rays.append(pt.ray_count()[0])
-    assert rays[0] == rays[1] == rays[2] > 0      # all kernels trace exactly the same rays
+    assert rays[0] == rays[1] == rays[2] == rays[3] > 0      # all kernels trace exactly the same rays
     pt.set_kernel(2)
     pt.set_tiling(16, 8, 1, 3)         # sharded: rank 1 of 3
     part = np.full((h, w, 3), -1.0, np.float32)
@@ -228,7 +229,7 @@ def test_edge_shapes(srt, w, h, depth, spp, tile, world):
     scene = pt_scene("cbox")
     want = H.OraclePT(scene, w, h, depth, True).epoch(2**40 + 12345, 2**31 - 3, spp)   # large seed / sample base
     pt = make_pt(srt, scene, w, h, depth, True)
-    for mode in (2, 4):
+    for mode in (2, 4, 5):
         pt.set_kernel(mode)
         img = np.full((h, w, 3), -7.0, np.float32)
         for rank in range(world):
