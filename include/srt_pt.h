@@ -107,14 +107,13 @@ int srt_pt_untile_device(srt_pt* pt, void* stream, const float* d_gathered, floa
 int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, const float* d_epoch, size_t nfloats,
                              uint32_t accumulator_samples);
 
-/* Kernel selection for render_epoch*: 0 = automatic (default: the persistent wave kernel — with wave-uniform
- * sweeps for scenes of <= 16 objects whose meshes are single BVH leaves, with the flattened per-lane walk of both
- * tree levels for other scenes of <= 31 objects — else the per-lane kernel with one lane per sample),
- * 1 = per-lane kernel, one lane per pixel (any scene), 2 = persistent wave kernel with wave-uniform sweeps
- * (<= 16 objects; fails otherwise), 3 = the same with in-kernel section stamps (diagnostic build, slower),
+/* Kernel selection for render_epoch*: 0 = automatic (default: the persistent wave kernel with wave-uniform
+ * sweeps for scenes of <= 16 objects whose meshes are single BVH leaves, else the per-lane kernel with one lane
+ * per sample), 1 = per-lane kernel, one lane per pixel (any scene), 2 = persistent wave kernel with wave-uniform
+ * sweeps (<= 16 objects; fails otherwise), 3 = the same with in-kernel section stamps (diagnostic build, slower),
  * 4 = per-lane kernel, one lane per sample (any scene), 5 = persistent wave kernel with the flattened per-lane
- * walk (<= 31 objects; fails otherwise).  All produce bit-identical images; the switch exists for A/B tests and
- * profiling. */
+ * walk of both tree levels (<= 31 objects; fails otherwise; srt_pt_hit then also goes through that walk).  All
+ * produce bit-identical images; the switch exists for A/B tests and profiling. */
 int srt_pt_set_kernel(srt_pt* pt, int mode);
 /* Mode 3 only: shader-clock cycles summed over waves per loop section
  * {refill, top-down sweep, leaf objects, combine, finish-direct, shade, terminate, 0}. */

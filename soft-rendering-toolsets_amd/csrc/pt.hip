@@ -293,9 +293,11 @@ int wave_trav(const srt_pt* pt) {
     if ((w.l_ref < 0 && w.l_cnt > kFlatMaxLeafObjects) || (w.r_ref < 0 && w.r_cnt > kFlatMaxLeafObjects)) flat_fits = false;
   if (m == 2 || m == 3) return sweeps_fit ? (blas ? 1 : 0) : -1;
   if (m == 5) return flat_fits ? 2 : -1;
-  // auto: sweeps for small scenes of single-leaf meshes; meshes with a real BVH<Triangle> go to the flattened walk
+  // auto: sweeps for small scenes of single-leaf meshes.  Scenes with a real BVH<Triangle> are bound by the vector
+  // memory path (64 lanes fetching 64-byte records from 64 different cache lines), where the lane-per-sample
+  // kernel is still ahead of the flattened walk on MI355X (325 vs 270 Mrays/s on the 131 k-triangle test scene)
   if (sweeps_fit && !blas) return 0;
-  return flat_fits ? 2 : -1;
+  return -1;
 }
 bool wave_kernel_applies(const srt_pt* pt) { return wave_trav(pt) >= 0; }
 
@@ -356,6 +358,8 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.groups = (n + kBurst - 1) / kBurst;
     P.total_units = px * P.groups; P.nlanes = nlanes;
     P.sample_out = pt->d_samples; P.records = pt->d_records;
+    P.flat_ready = getenv("SRT_FLAT_READY") ? (uint32_t)atoi(getenv("SRT_FLAT_READY")) : kFlatReady;
+    P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;
     P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = pt->d_queue + 1;
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));

@@ -23,6 +23,12 @@
 
 namespace srt {
 
+// Keeps a value in a VGPR of its own at this point (an empty asm the optimizer cannot look through).  The CPU build of
+// the test harness (tests/host_emu) defines it away.
+#ifndef SRT_PIN_VGPR
+#define SRT_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
 // fl: bit 0 hitboth, bit 1 "nearer child done", bit 2 its hit flag, bits 3.. its object slot.
 // Before the nearer child returns a/b hold cur_far_t; afterwards a = its distance, b = its triangle.
 struct FlatFrame { int32_t second; float a; uint32_t b; uint32_t fl; };
@@ -37,18 +43,15 @@ SRT_DEV int32_t flat_tlas_ref(int32_t ref, uint32_t cnt) {
   return ref >= 0 ? ref : ~(int32_t)((((uint32_t)~ref) << 3) | (cnt < kFlatMaxLeafObjects ? cnt : kFlatMaxLeafObjects));
 }
 
-// scene.hit for up to three rays sharing the origin `org` (slot r is traced iff act[r]); results as ids.
-SRT_DEV void flat_trace3(const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1, bool act0, bool act1, bool act2,
-                         Hit& res0, Hit& res1, Hit& res2) {
-  FlatFrame stack[kFlatStack];
-  const bool toplist = !S.use_bvh || S.wave_q == 0;   // List<Object>, or a BVH<Object> whose root is a leaf
-  const uint32_t list_n = (S.use_bvh && S.tlas_nodes == 0) ? 0u : S.nobjects;
-
-  uint32_t r = act0 ? 0u : (act1 ? 1u : (act2 ? 2u : 3u));
+// Per-lane state of the walk.  It lives in registers across iterations of the caller's loop, so a wave may leave
+// the walk while some lanes are still inside a tree (to shade the lanes that are finished) and come back later.
+struct FlatState {
+  uint32_t r = 3;                           // slot being traced (3: none left)
   uint32_t mode = FM_DONE;
+  bool act1 = false, act2 = false;          // slots 1, 2 still to do
   // ray of the tree the lane is in (world ray at TLAS level, object-space ray inside a mesh)
-  V3 co = org, cd = d0, cinv = v3(0, 0, 0);
-  float b0 = cb0, b1 = cb1, tx = 0.0f, ty = 0.0f;
+  V3 co, cd, cinv;
+  float b0 = 0.0f, b1 = 0.0f, tx = 0.0f, ty = 0.0f;
   int32_t cur = 0;
   int sp = 0, base_sp = 0;
   uint32_t level = 0;                       // 0 TLAS / object list, 1 inside a mesh's BVH<Triangle>
@@ -56,168 +59,243 @@ SRT_DEV void flat_trace3(const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0
   uint32_t rec_base = 0, tri_base = 0;      // of the mesh being walked
   bool xf = false;                          // ... and whether it has a transform
   Hit acc, ret;                             // leaf accumulator (TLAS level) / result of the subtree just finished
-  acc.hit = false; acc.dist = 0.0f; acc.obj = 0; acc.tri = 0;
-  ret = acc;
-  res0 = acc; res1 = acc; res2 = acc;
+  Hit res0, res1, res2;
+};
 
-#define SRT_FLAT_BEGIN_RAY()                                                                   \
-  {                                                                                            \
-    co = org; cd = (r == 0u) ? d0 : ((r == 1u) ? d1 : d2); b0 = cb0; b1 = cb1;                 \
-    cinv = v3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);                                          \
-    level = 0; sp = 0; base_sp = 0;                                                            \
-    acc.hit = false; acc.dist = 0.0f; acc.obj = 0; acc.tri = 0;                                \
-    if (toplist) { obj_i = 0; obj_end = list_n; mode = FM_OBJECT; }                            \
-    else {                                                                                     \
-      const float dn_ = norm(cd);                                                              \
-      tx = b0 / dn_; ty = b1 / dn_;            /* Vec2 times = dist_bounds / dir.norm() */      \
-      cur = 0; mode = FM_NODE;                                                                 \
-    }                                                                                          \
+SRT_DEV V3 flat_pick(uint32_t r, V3 d0, V3 d1, V3 d2) {
+  return v3(r == 0u ? d0.x : (r == 1u ? d1.x : d2.x), r == 0u ? d0.y : (r == 1u ? d1.y : d2.y), r == 0u ? d0.z : (r == 1u ? d1.z : d2.z));
+}
+SRT_DEV Hit flat_select(bool c, const Hit& a, const Hit& b) {
+  Hit h; h.hit = c ? a.hit : b.hit; h.dist = c ? a.dist : b.dist; h.obj = c ? a.obj : b.obj; h.tri = c ? a.tri : b.tri; return h;
+}
+SRT_DEV Hit flat_no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
+
+// Start on slot F.r (< 3) of the batch.
+SRT_DEV void flat_begin_ray(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1) {
+  const bool toplist = !S.use_bvh || S.wave_q == 0;   // List<Object>, or a BVH<Object> whose root is a leaf
+  F.co = org; F.cd = flat_pick(F.r, d0, d1, d2); F.b0 = cb0; F.b1 = cb1;
+  F.cinv = v3(1.0f / F.cd.x, 1.0f / F.cd.y, 1.0f / F.cd.z);
+  F.level = 0; F.sp = 0; F.base_sp = 0;
+  F.acc = flat_no_hit();
+  if (toplist) {
+    F.obj_i = 0; F.obj_end = (S.use_bvh && S.tlas_nodes == 0) ? 0u : S.nobjects; F.mode = FM_OBJECT;
+  } else {
+    const float dn = norm(F.cd);
+    F.tx = F.b0 / dn; F.ty = F.b1 / dn;     // Vec2 times = dist_bounds / dir.norm()
+    F.cur = 0; F.mode = FM_NODE;
   }
+}
 
-  if (r < 3u) SRT_FLAT_BEGIN_RAY()
+// Start a batch: slot r is traced iff act_r.
+SRT_DEV void flat_begin(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1, bool act0, bool act1,
+                        bool act2) {
+  F.res0 = flat_no_hit(); F.res1 = F.res0; F.res2 = F.res0; F.ret = F.res0;
+  F.act1 = act1; F.act2 = act2;
+  F.r = act0 ? 0u : (act1 ? 1u : (act2 ? 2u : 3u));
+  F.mode = FM_DONE;
+  if (F.r < 3u) flat_begin_ray(F, S, org, d0, d1, d2, cb0, cb1);
+}
 
-  while (__ballot(mode != FM_DONE) != 0ull) {
-    // ------------------------------------------------------------------ NODE
-    if (mode == FM_NODE) {
-      if (cur >= 0) {
-        const WaveInterior* __restrict__ rp = level ? (S.blas_recs + rec_base) : S.wave_tlas;
-        const WaveInterior W = rp[cur];
-        float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
-        const bool hl = box_hit_rec(W.boxl, co, cinv, t1x, t1y);
-        const bool hr = box_hit_rec(W.boxr, co, cinv, t2x, t2y);
-        if (hl || hr) {
-          const int32_t lref = level ? W.l_ref : flat_tlas_ref(W.l_ref, W.l_cnt);
-          const int32_t rref = level ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
-          const bool hb = hl && hr;
-          const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
-          FlatFrame f;
-          f.second = cl ? rref : lref;
-          f.a = hb ? (cl ? t2x : t1x) : b0;          // cur_far_t: the other child's times, or ray.dist_bounds
-          f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : b1);
-          f.fl = hb ? 1u : 0u;
-          stack[sp++] = f;
-          cur = cl ? lref : rref;
-          tx = cl ? t1x : t2x;
-          ty = cl ? t1y : t2y;
-        } else {
-          ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
-          mode = FM_UNWIND;
-        }
-      } else if (level) {                              // leaf of a BVH<Triangle>: fold its triangles in order
-        const uint32_t packed = (uint32_t)~cur;
-        const uint32_t first = tri_base + (packed >> 3), n = packed & 7u;
-        Ray ray; ray.o = co; ray.d = cd; ray.b0 = b0; ray.b1 = b1;
-        ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
-        for (uint32_t i = 0; i < n; i++) {
-          const TriHit th = tri_hit(S.tris[first + i], ray);
-          fold(ret, th.hit, th.dist, 0, first + i);
-        }
-        mode = FM_UNWIND;
-      } else {                                         // leaf of the BVH<Object>
-        const uint32_t packed = (uint32_t)~cur;
-        obj_i = packed >> 3; obj_end = obj_i + (packed & 7u);
-        acc.hit = false; acc.dist = 0.0f; acc.obj = 0; acc.tri = 0;
-        mode = FM_OBJECT;
-      }
+// ---- the steps of the walk; each requires the state named in its comment ----
+
+// mode == NODE, cur >= 0: an interior record of the current tree.
+SRT_DEV void flat_interior(FlatState& F, FlatFrame* stack, const DScene& S) {
+  const WaveInterior* __restrict__ rp = F.level ? (S.blas_recs + F.rec_base) : S.wave_tlas;
+  const WaveInterior W = rp[F.cur];
+  float t1x = F.tx, t1y = F.ty, t2x = F.tx, t2y = F.ty;
+  const bool hl = box_hit_rec(W.boxl, F.co, F.cinv, t1x, t1y);
+  const bool hr = box_hit_rec(W.boxr, F.co, F.cinv, t2x, t2y);
+  if (hl || hr) {
+    const int32_t lref = F.level ? W.l_ref : flat_tlas_ref(W.l_ref, W.l_cnt);
+    const int32_t rref = F.level ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
+    const bool hb = hl && hr;
+    const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
+    FlatFrame f;
+    f.second = cl ? rref : lref;
+    f.a = hb ? (cl ? t2x : t1x) : F.b0;        // cur_far_t: the other child's times, or ray.dist_bounds
+    f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : F.b1);
+    f.fl = hb ? 1u : 0u;
+    stack[F.sp++] = f;
+    F.cur = cl ? lref : rref;
+    F.tx = cl ? t1x : t2x;
+    F.ty = cl ? t1y : t2y;
+  } else {
+    F.ret = flat_no_hit();
+    F.mode = FM_UNWIND;
+  }
+}
+
+// mode == NODE, cur < 0: a leaf.
+SRT_DEV void flat_leaf(FlatState& F, const DScene& S) {
+  const uint32_t packed = (uint32_t)~F.cur;
+  if (F.level) {                                   // BVH<Triangle>: fold its triangles in order
+    const uint32_t first = F.tri_base + (packed >> 3), n = packed & 7u;
+    Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
+    F.ret = flat_no_hit();
+    for (uint32_t i = 0; i < n; i++) {
+      const TriHit th = tri_hit(S.tris[first + i], ray);
+      fold(F.ret, th.hit, th.dist, 0, first + i);
     }
-    // ------------------------------------------------------------------ OBJECT (Object::hit, rays/object.h:57-65)
-    if (mode == FM_OBJECT) {
-      if (obj_i >= obj_end) {
-        ret = acc;
-        mode = FM_UNWIND;
-      } else {
-        const Object& o = S.objects[obj_i];
-        Ray ray; ray.o = co; ray.d = cd; ray.b0 = b0; ray.b1 = b1;     // level 0: the world ray
-        const bool oxf = o.has_trans != 0;
-        if (oxf) ray_transform(ray, o.itrans);
-        if (o.kind != OBJ_SPHERE && o.use_bvh && o.nrec > 0) {        // Tri_Mesh with a real BVH: walk it
-          co = ray.o; cd = ray.d; b0 = ray.b0; b1 = ray.b1;
-          cinv = v3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-          const float dn = norm(cd);
-          tx = b0 / dn; ty = b1 / dn;
-          level = 1; rec_base = o.rec_base; tri_base = o.tri_base; xf = oxf;
-          base_sp = sp; cur = 0;
-          mode = FM_NODE;
-        } else {
-          bool hit; float dist; uint32_t tri = 0; V3 pos;
-          if (o.kind == OBJ_SPHERE) {
-            const SphHit sh = sphere_hit(o.radius, ray);
-            hit = sh.hit;
-            pos = ray_at(ray, sh.t);
-            dist = fabsf(norm(pos - ray.o));
-          } else {                                     // one leaf / List<Triangle>: ordered fold over every triangle
-            Hit best; best.hit = false; best.dist = 0.0f; best.obj = 0; best.tri = 0;
-            float bt = 0.0f;
-            const uint32_t n = (o.use_bvh && o.nnodes == 0) ? 0u : o.ntri;
-            for (uint32_t t = 0; t < n; t++) {
-              const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
-              const bool keep = left_wins(best.hit, best.dist, th.hit, th.dist);
-              bt = keep ? bt : (th.hit ? th.t : 0.0f);
-              fold(best, th.hit, th.dist, 0, o.tri_base + t);
-            }
-            hit = best.hit; dist = best.dist; tri = best.tri;
-            pos = ray_at(ray, bt);
-          }
-          if (hit && oxf) {                            // Trace::transform: distance = |T*position - T*origin|
-            const V3 pw = mat_point(o.trans, pos);
-            const V3 ow = mat_point(o.trans, ray.o);
-            dist = norm(pw - ow);
-          }
-          fold(acc, hit, dist, obj_i, tri);
-          obj_i++;
-        }
-      }
+    F.mode = FM_UNWIND;
+  } else {                                         // BVH<Object>: start on its objects
+    F.obj_i = packed >> 3; F.obj_end = F.obj_i + (packed & 7u);
+    F.acc = flat_no_hit();
+    F.mode = FM_OBJECT;
+  }
+}
+
+// mode == OBJECT: Object::hit (rays/object.h:57-65) of the next object of the leaf / list, or the end of the leaf.
+SRT_DEV void flat_object(FlatState& F, const DScene& S) {
+  if (F.obj_i >= F.obj_end) {
+    F.ret = F.acc;
+    F.mode = FM_UNWIND;
+    return;
+  }
+  const Object& o = S.objects[F.obj_i];
+  Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;     // level 0: the world ray
+  const bool oxf = o.has_trans != 0;
+  if (oxf) ray_transform(ray, o.itrans);
+  if (o.kind != OBJ_SPHERE && o.use_bvh && o.nrec > 0) {        // Tri_Mesh with a real BVH: walk it
+    F.co = ray.o; F.cd = ray.d; F.b0 = ray.b0; F.b1 = ray.b1;
+    F.cinv = v3(1.0f / F.cd.x, 1.0f / F.cd.y, 1.0f / F.cd.z);
+    const float dn = norm(F.cd);
+    F.tx = F.b0 / dn; F.ty = F.b1 / dn;
+    F.level = 1; F.rec_base = o.rec_base; F.tri_base = o.tri_base; F.xf = oxf;
+    F.base_sp = F.sp; F.cur = 0;
+    F.mode = FM_NODE;
+    return;
+  }
+  bool hit; float dist; uint32_t tri = 0; V3 pos;
+  if (o.kind == OBJ_SPHERE) {
+    const SphHit sh = sphere_hit(o.radius, ray);
+    hit = sh.hit;
+    pos = ray_at(ray, sh.t);
+    dist = fabsf(norm(pos - ray.o));
+  } else {                                         // one leaf / List<Triangle>: ordered fold over every triangle
+    Hit best = flat_no_hit();
+    float bt = 0.0f;
+    const uint32_t n = (o.use_bvh && o.nnodes == 0) ? 0u : o.ntri;
+    for (uint32_t t = 0; t < n; t++) {
+      const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
+      const bool keep = left_wins(best.hit, best.dist, th.hit, th.dist);
+      bt = keep ? bt : (th.hit ? th.t : 0.0f);
+      fold(best, th.hit, th.dist, 0, o.tri_base + t);
     }
-    // ------------------------------------------------------------------ UNWIND
-    if (mode == FM_UNWIND) {
-      if (level && sp == base_sp) {                    // the mesh's tree is done: finish Object::hit, back to the leaf
-        bool hit = ret.hit; float dist = ret.dist; const uint32_t tri = ret.tri;
-        if (hit && xf) {
-          const Object& o = S.objects[obj_i];
-          Ray ray; ray.o = co; ray.d = cd; ray.b0 = b0; ray.b1 = b1;
-          const TriHit th = tri_hit(S.tris[tri], ray);  // (u, v, t) of the winner: same arithmetic, same bits
-          const V3 pos = ray_at(ray, th.t);
-          const V3 pw = mat_point(o.trans, pos);
-          const V3 ow = mat_point(o.trans, ray.o);
-          dist = norm(pw - ow);
-        }
-        fold(acc, hit, dist, obj_i, tri);
-        obj_i++;
-        level = 0;
-        co = org; cd = (r == 0u) ? d0 : ((r == 1u) ? d1 : d2); b0 = cb0; b1 = cb1;
-        cinv = v3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-        mode = FM_OBJECT;
-      } else if (sp == 0) {                            // the query of ray r is complete
-        if (r == 0u) res0 = ret; else if (r == 1u) res1 = ret; else res2 = ret;
-        r = (r == 0u) ? (act1 ? 1u : (act2 ? 2u : 3u)) : ((r == 1u) ? (act2 ? 2u : 3u) : 3u);
-        mode = FM_DONE;
-        if (r < 3u) SRT_FLAT_BEGIN_RAY()
-      } else {
-        const FlatFrame f = stack[sp - 1];
-        const bool near_done = (f.fl & 2u) != 0;
-        // student/bvh.inl:216: after the nearer child, also visit the farther one iff ...
-        const bool visit = !near_done && (f.a < ret.dist || (!ret.hit && (f.fl & 1u) != 0));
-        if (visit) {
-          FlatFrame g;                                 // keep the nearer child's result in the frame
-          g.second = f.second; g.a = ret.dist; g.b = ret.tri;
-          g.fl = f.fl | 2u | (ret.hit ? 4u : 0u) | (ret.obj << 3);
-          stack[sp - 1] = g;
-          cur = f.second; tx = f.a; ty = __uint_as_float(f.b);
-          mode = FM_NODE;
-        } else {
-          // nearer child only: this node's result is `ret` as it stands; after the farther child:
-          // Trace::min(nearer, farther) - the nearer result wins only when strictly closer (a miss keeps ret's zeros)
-          const bool saved = near_done && left_wins((f.fl & 4u) != 0, f.a, ret.hit, ret.dist);
-          ret.hit = saved ? true : ret.hit;
-          ret.dist = saved ? f.a : ret.dist;
-          ret.obj = saved ? (f.fl >> 3) : ret.obj;
-          ret.tri = saved ? f.b : ret.tri;
-          sp--;
-        }
+    hit = best.hit; dist = best.dist; tri = best.tri;
+    pos = ray_at(ray, bt);
+  }
+  if (hit && oxf) {                                // Trace::transform: distance = |T*position - T*origin|
+    const V3 pw = mat_point(o.trans, pos);
+    const V3 ow = mat_point(o.trans, ray.o);
+    dist = norm(pw - ow);
+  }
+  fold(F.acc, hit, dist, F.obj_i, tri);
+  F.obj_i++;
+}
+
+// mode == UNWIND: is the next thing to do an ordinary frame (as opposed to leaving a mesh or finishing the ray)?
+SRT_DEV bool flat_plain_frame(const FlatState& F) { return F.sp != 0 && !(F.level && F.sp == F.base_sp); }
+
+// mode == UNWIND with an ordinary frame on top.
+SRT_DEV void flat_pop(FlatState& F, FlatFrame* stack) {
+  const FlatFrame f = stack[F.sp - 1];
+  // hipcc 7.2 -O2/-O3 (gfx950) has been seen to drop the `cur = f.second` below when this function is inlined
+  // behind flat_interior (the lane then re-walks the nearer child instead of the farther one; -O1 and the host
+  // build are right, step traces compared in round 1).  Pinning the loaded value in its own VGPR avoids it; the
+  // GPU parity tests (hit() through this walk vs the nested form, and every epoch test) guard against a return.
+  int32_t second = f.second;
+  SRT_PIN_VGPR(second);
+  const bool near_done = (f.fl & 2u) != 0;
+  // student/bvh.inl:216: after the nearer child, also visit the farther one iff ...
+  const bool visit = !near_done && (f.a < F.ret.dist || (!F.ret.hit && (f.fl & 1u) != 0));
+  if (visit) {
+    FlatFrame g;                                   // keep the nearer child's result in the frame
+    g.second = second; g.a = F.ret.dist; g.b = F.ret.tri;
+    g.fl = f.fl | 2u | (F.ret.hit ? 4u : 0u) | (F.ret.obj << 3);
+    stack[F.sp - 1] = g;
+    F.cur = second; F.tx = f.a; F.ty = __uint_as_float(f.b);
+    F.mode = FM_NODE;
+  } else {
+    // nearer child only: this node's result is `ret` as it stands; after the farther child:
+    // Trace::min(nearer, farther) - the nearer result wins only when strictly closer (a miss keeps ret's zeros)
+    const bool saved = near_done && left_wins((f.fl & 4u) != 0, f.a, F.ret.hit, F.ret.dist);
+    F.ret.hit = saved ? true : F.ret.hit;
+    F.ret.dist = saved ? f.a : F.ret.dist;
+    F.ret.obj = saved ? (f.fl >> 3) : F.ret.obj;
+    F.ret.tri = saved ? f.b : F.ret.tri;
+    F.sp--;
+  }
+}
+
+// mode == UNWIND without an ordinary frame: the mesh's tree is done (finish Object::hit, back to the leaf's
+// objects), or the whole query of slot r is (store it, start the next slot).
+SRT_DEV void flat_exit(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1) {
+  if (F.level) {
+    bool hit = F.ret.hit; float dist = F.ret.dist; const uint32_t tri = F.ret.tri;
+    if (hit && F.xf) {
+      const Object& o = S.objects[F.obj_i];
+      Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
+      const TriHit th = tri_hit(S.tris[tri], ray);  // (u, v, t) of the winner: same arithmetic, same bits
+      const V3 pos = ray_at(ray, th.t);
+      const V3 pw = mat_point(o.trans, pos);
+      const V3 ow = mat_point(o.trans, ray.o);
+      dist = norm(pw - ow);
+    }
+    fold(F.acc, hit, dist, F.obj_i, tri);
+    F.obj_i++;
+    F.level = 0;
+    F.co = org; F.cd = flat_pick(F.r, d0, d1, d2); F.b0 = cb0; F.b1 = cb1;
+    F.cinv = v3(1.0f / F.cd.x, 1.0f / F.cd.y, 1.0f / F.cd.z);
+    F.mode = FM_OBJECT;
+  } else {
+    // (value selects, not conditional stores: a store through a selected address would pin the whole state in memory)
+    F.res0 = flat_select(F.r == 0u, F.ret, F.res0);
+    F.res1 = flat_select(F.r == 1u, F.ret, F.res1);
+    F.res2 = flat_select(F.r == 2u, F.ret, F.res2);
+    F.r = (F.r == 0u) ? (F.act1 ? 1u : (F.act2 ? 2u : 3u)) : ((F.r == 1u) ? (F.act2 ? 2u : 3u) : 3u);
+    F.mode = FM_DONE;
+    if (F.r < 3u) flat_begin_ray(F, S, org, d0, d1, d2, cb0, cb1);
+  }
+}
+
+// The walk of a whole wave, "while-while" style: interior steps - the bulk of the work, and uniform in cost - are
+// repeated as long as at least `interior_min` lanes take part (lanes that reached a leaf or an object wait);
+// then the waiting lanes do their leaf / object / exit step together.  Returns when no lane is walking any more, or
+// when `ready_min` lanes with `counts` set have finished their batch (the caller then shades / refills those and
+// calls again; the other lanes keep their place in the tree).
+SRT_DEV void flat_run(FlatState& F, FlatFrame* stack, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1,
+                      bool counts, uint32_t ready_min, uint32_t interior_min) {
+  for (;;) {
+    if (__ballot(F.mode != FM_DONE) == 0ull) break;
+    if ((uint32_t)__popcll(__ballot(counts && F.mode == FM_DONE)) >= ready_min) break;
+    for (;;) {
+      const bool can = F.mode == FM_NODE && F.cur >= 0;
+      if (__ballot(can) == 0ull) break;
+      if (can) {
+        flat_interior(F, stack, S);
+        while (F.mode == FM_UNWIND && flat_plain_frame(F)) flat_pop(F, stack);   // a double miss: straight back to a node
       }
+      if ((uint32_t)__popcll(__ballot(F.mode == FM_NODE && F.cur >= 0)) < interior_min) break;
+    }
+    if (F.mode == FM_NODE && F.cur < 0) flat_leaf(F, S);
+    if (F.mode == FM_OBJECT) flat_object(F, S);
+    while (F.mode == FM_UNWIND) {
+      if (flat_plain_frame(F)) flat_pop(F, stack);
+      else flat_exit(F, S, org, d0, d1, d2, cb0, cb1);
     }
   }
-#undef SRT_FLAT_BEGIN_RAY
+}
+
+constexpr uint32_t kFlatInteriorMin = 16;
+
+// scene.hit for up to three rays sharing the origin `org` (slot r is traced iff act_r), run to completion.
+SRT_DEV void flat_trace3(const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1, bool act0, bool act1, bool act2,
+                         Hit& res0, Hit& res1, Hit& res2) {
+  FlatFrame stack[kFlatStack];
+  FlatState F;
+  flat_begin(F, S, org, d0, d1, d2, cb0, cb1, act0, act1, act2);
+  flat_run(F, stack, S, org, d0, d1, d2, cb0, cb1, false, 65u, kFlatInteriorMin);
+  res0 = F.res0; res1 = F.res1; res2 = F.res2;
 }
 
 }  // namespace srt

@@ -45,6 +45,7 @@ constexpr uint32_t kWaveMaxObjects = 16;
 constexpr uint32_t kChunk = 512;          // units (sample triples) a wave reserves per queue atomic
 constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
+constexpr uint32_t kFlatReady = 16;        // TRAV 2: lanes with a finished batch that make the wave leave the walk
 constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
 
 struct WaveParams {
@@ -59,7 +60,9 @@ struct WaveParams {
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
-  unsigned long long* stamps;       // STAMP build only: per-section cycle sums
+  unsigned long long* stamps;
+  uint32_t flat_ready;       // TRAV 2: lanes with a finished batch that make the wave leave the walk
+  uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
 };
 
 // Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
@@ -272,6 +275,12 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
   float pdf4 = 1.0f, pdf_area = 0.0f;
   bool discrete = false;
 
+  // TRAV == 2: the flattened walk's per-lane state and stack persist across iterations of the loop below, so the
+  // wave can stop walking once kFlatReady lanes have a finished batch, shade / refill those, and resume the rest
+  FlatState FS;
+  FlatFrame fstack[TRAV == 2 ? kFlatStack : 1];
+  bool need_begin = false;                               // a new batch (camera burst or bounce) waits to be started
+
   // wave-uniform queue window
   uint32_t chunk_next = 0, chunk_end = 0;
   bool queue_empty = false;
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
           }
           actA = s_count > 1;                           // slot usage of a burst: ray j exists iff j < s_count
           actB = s_count > 2;
+          need_begin = true;
         }
       }
     }
@@ -339,14 +349,21 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
     SECTION_END(ST_REFILL)
 
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
-    cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
+    if (TRAV != 2) cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
     const float rb0[3] = {cb0, cb0, cb0};
     const float rb1[3] = {cb1, cb1, cb1};
     Hit res[3];
+    bool batch_ready = alive;                            // the lane's batch has been traced completely
     if (TRAV == 2) {
       // general scenes: one flattened per-lane walk over both tree levels for the slots that carry a ray
-      const bool a0 = alive && (burst || actA), a1 = alive && (burst ? actA : actB), a2 = alive && (burst ? actB : true);
-      flat_trace3(S, org, d[0], d[1], d[2], cb0, cb1, a0, a1, a2, res[0], res[1], res[2]);
+      if (need_begin) {
+        cnt.v[C_RAYS] += 1u + (actA ? 1u : 0u) + (actB ? 1u : 0u);
+        flat_begin(FS, S, org, d[0], d[1], d[2], cb0, cb1, burst || actA, burst ? actA : actB, burst ? actB : true);
+        need_begin = false;
+      }
+      flat_run(FS, fstack, S, org, d[0], d[1], d[2], cb0, cb1, alive, P.flat_ready, P.flat_interior);
+      batch_ready = alive && FS.mode == FM_DONE;
+      res[0] = FS.res0; res[1] = FS.res1; res[2] = FS.res2;
       SECTION_END(ST_LEAVES)
     } else if (Q == 0) {
       // List<Object>::hit, or a BVH<Object> whose root is a leaf: ordered fold over every object
@@ -448,7 +465,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
     }
 
     // ---------------- 3. finish the previous bounce / unpack the burst, then terminate or shade ----------------
-    if (alive) {
+    if (batch_ready) {
       uint32_t chit;                                    // packed closest hit that decides how the current path goes on
       if (burst) {
         // burst order: slot 0 = sample s_first (continues now), slots 1, 2 = the next samples (parked)
@@ -573,6 +590,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
         d[1] = unit(chosen);
         d[2] = unit(world_in2);
         cb0 = kEps; cb1 = FLT_MAX;
+        need_begin = true;
       }
     }
     SECTION_END(ST_SHADE)

@@ -10,7 +10,9 @@
 #define __host__
 #define __global__
 #define __forceinline__ inline
+#define SRT_PIN_VGPR(x) ((void)(x))
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }   // a "wave" of one lane
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 #endif

@@ -59,6 +59,9 @@ def test_hip_matches_reference_golden(srt, path):
     assert np.array_equal(draws, g["draws"]), "RNG draw ledger differs from the reference"
     org, d, b = random_rays(seed + 1, 2048)
     assert bits_equal(pt.hit(org, d, b), g["hits"]), "scene.hit differs from the reference"
+    pt.set_kernel(5)                     # the same query through the flattened per-lane walk (pt_flat.h)
+    assert bits_equal(pt.hit(org, d, b), g["hits"]), "scene.hit through the flattened walk differs from the reference"
+    pt.set_kernel(0)
     if "epoch" in g:
         ew, eh, spp, base = (int(x) for x in g["epoch_meta"])
         pt.set_params(ew, eh, spp, depth, bool(use_bvh))
