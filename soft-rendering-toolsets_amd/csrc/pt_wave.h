@@ -42,7 +42,7 @@
 namespace srt {
 
 constexpr uint32_t kWaveMaxObjects = 16;
-constexpr uint32_t kChunk = 512;          // units (sample triples) a wave reserves per queue atomic
+constexpr uint32_t kChunk = 64;           // units (sample triples) a wave reserves per queue atomic (WaveParams::chunk)
 constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
 constexpr uint32_t kFlatReady = 16;        // TRAV 2: lanes with a finished batch that make the wave leave the walk
@@ -61,6 +61,7 @@ struct WaveParams {
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
   unsigned long long* stamps;
+  uint32_t chunk;            // units a wave reserves per queue atomic
   uint32_t flat_ready;       // TRAV 2: lanes with a finished batch that make the wave leave the walk
   uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
 };
@@ -296,11 +297,11 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
         if (chunk_next == chunk_end) {
           if (queue_empty) break;
           unsigned long long start = 0;
-          if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)kChunk);
+          if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)P.chunk);
           start = __shfl(start, 0);
           if (start >= P.total_units) { queue_empty = true; break; }
           chunk_next = (uint32_t)start;
-          chunk_end = (uint32_t)(start + kChunk < P.total_units ? start + kChunk : P.total_units);
+          chunk_end = (uint32_t)(start + P.chunk < P.total_units ? start + P.chunk : P.total_units);
         }
         const uint32_t avail = chunk_end - chunk_next;
         const uint32_t take = avail < want - given ? avail : want - given;
