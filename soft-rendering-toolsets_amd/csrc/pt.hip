@@ -355,8 +355,10 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     WaveParams P;
     P.T = T; P.seed = seed; P.sample_base = sample_base + done; P.samples = n;
-    P.groups = (n + kBurst - 1) / kBurst;
-    P.total_units = px * P.groups; P.nlanes = nlanes;
+    P.singles = (n >= 4 * kBurst) ? kBurst + n % kBurst : n % kBurst;   // 3..5 of a big launch's samples per pixel, else the remainder
+    P.groups3 = (n - P.singles) / kBurst;
+    P.units3 = px * P.groups3;
+    P.total_units = px * (P.groups3 + P.singles); P.nlanes = nlanes;
     P.sample_out = pt->d_samples; P.records = pt->d_records;
     // one unit per lane per queue atomic: with the 512-unit grabs of the first version the last grabs decided the
     // launch time (a 1/8 image shard ran at 56 % of the full-image rate; 83 % with 64, and the full image gained 6 %)

@@ -29,7 +29,8 @@
 // After a burst the first sample's path goes on immediately, the other two camera hits are parked (one
 // packed dword each) and picked up — without another trace — as soon as the current path ends.  All three
 // slots of (almost) every batch therefore carry useful rays.  Work units are groups of three samples pulled
-// from a global queue (one atomic per 512 groups per wave): persistent threads with per-lane path
+// from a global queue (one atomic per 64 units per wave; the last few samples of every pixel are queued as
+// single-sample units at the very end to keep the tail of a launch short): persistent threads with per-lane path
 // regeneration, no tail of idle lanes.  Every sample's radiance is written to a
 // per-unit buffer; pt_reduce_kernel then adds the samples of a pixel in sample order, exactly as do_trace
 // does (rays/pathtracer.cpp:216-226), so the image does not depend on which lane traced what.
@@ -53,8 +54,9 @@ struct WaveParams {
   uint64_t seed;
   uint32_t sample_base;      // first sample index of this launch
   uint32_t samples;          // samples per pixel in this launch
-  uint32_t groups;           // units per pixel = ceil(samples / kBurst)
-  uint32_t total_units;      // local_tiles * tile_w * tile_h * groups
+  uint32_t groups3, singles; // units per pixel: groups3 full bursts of kBurst samples, then `singles` one-sample units
+  uint32_t units3;           // pixels * groups3: units below this index are bursts
+  uint32_t total_units;      // pixels * (groups3 + singles)
   uint32_t nlanes;           // threads of the whole grid (record scratch stride)
   float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
@@ -311,15 +313,20 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
       }
       if (my_unit != kMissTri) {
         uint32_t x, y;
-        const uint32_t groups = opq(P.groups), nsamples = opq(P.samples), img_w = opq(S.w), img_h = opq(S.h);
-        unit_pixel(opq(P.T), my_unit / groups, x, y);
+        // queue order: first every pixel's full triples, then the single-sample units (short work items last, so
+        // the end of the launch does not wait for a lane that drew three long paths)
+        const uint32_t g3 = opq(P.groups3), g1 = opq(P.singles), n3 = opq(P.units3), img_w = opq(S.w), img_h = opq(S.h);
+        uint32_t u_pixel, u_first, u_count;
+        if (my_unit < n3) { u_pixel = my_unit / g3; u_first = (my_unit % g3) * kBurst; u_count = kBurst; }
+        else { const uint32_t v = my_unit - n3; u_pixel = v / g1; u_first = g3 * kBurst + v % g1; u_count = 1u; }
+        unit_pixel(opq(P.T), u_pixel, x, y);
         if (x < img_w && y < img_h) {                   // padding pixels of edge tiles are never read
           alive = true;
           burst = true;
           px = x; py = y;
-          pixel_slot = my_unit / groups;
-          s_first = (my_unit % groups) * kBurst;
-          s_count = nsamples - s_first < kBurst ? nsamples - s_first : kBurst;
+          pixel_slot = u_pixel;
+          s_first = u_first;
+          s_count = u_count;
           s_cur = s_first;
           level = 0;
           depth = S.max_depth;
