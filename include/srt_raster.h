@@ -45,13 +45,17 @@ typedef enum srt_status {
 /* Primitive kinds of the ordered stream. */
 enum {
     SRT_PRIM_TRIANGLE = 1, /* rasterize_triangle(x0,y0,x1,y1,x2,y2,color) — args already narrowed to float */
-    SRT_PRIM_POINT = 2     /* rasterize_point(x,y,color) — args are double, sr*sr block fill */
+    SRT_PRIM_POINT = 2,    /* rasterize_point(x,y,color) — args are double, sr*sr block fill */
+    SRT_PRIM_IMAGE = 3     /* rasterize_image(x0,y0,x1,y1,tex) — tri[0..3] = the four float parameters, `reserved` =
+                              texture id from srt_raster_add_texture; sampled with Sampler2DImp::sample_trilinear */
 };
+
+#define SRT_MAX_MIP_LEVELS 14 /* kMaxMipLevels, D/src/texture.h:9 */
 
 /* One 48-byte record of the ordered stream. Screen-space coordinates (pixels). */
 typedef struct srt_prim {
     uint32_t kind;
-    uint32_t reserved; /* must be 0 */
+    uint32_t reserved; /* 0; for SRT_PRIM_IMAGE the texture id */
     union {
         float tri[6];     /* x0 y0 x1 y1 x2 y2 — the six float parameters of rasterize_triangle */
         double point[2];  /* x y — the two double parameters of rasterize_point */

@@ -30,6 +30,7 @@ typedef struct {
     uint64_t tests_in;   /* ... of which inside the sample grid */
     uint64_t frags;      /* covered in-bounds fill_sample calls from rasterize_triangle */
     uint64_t pts;        /* in-bounds fill_sample calls from rasterize_point */
+    uint64_t img;        /* in-bounds fill_sample calls from rasterize_image */
 } oracle_raster;
 
 /* std::min / std::max as libstdc++ defines them (argument order matters for NaN / -0). */
@@ -113,6 +114,148 @@ static void rasterize_point(oracle_raster* o, double x, double y, const float co
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Images: rasterize_image (software_renderer.cpp:540-570) + Sampler2DImp (texture.cpp:53-193).
+ * A texture is a mip chain of RGBA8 levels.  Reads past the end of a level's texel vector (the reference
+ * indexes column `width` and row `height` at the right / bottom half-texel border, texture.cpp:158-166) are
+ * undefined there; here - and in the HIP kernel, and in the reference build the goldens come from, whose
+ * vectors get zeroed slack - they read zeros.  A column index of `width` inside the buffer wraps to the next
+ * row exactly as in the reference.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t nlevels;
+    uint32_t width[SRT_MAX_MIP_LEVELS], height[SRT_MAX_MIP_LEVELS];
+    const uint8_t* texels[SRT_MAX_MIP_LEVELS];
+} oracle_texture;
+
+/* GetColorFromTexture, texture.cpp:19-25 (x, y are the float arguments converted to int by the call) */
+static void get_texel(const oracle_texture* t, int level, int x, int y, float c[4]) {
+    size_t w = t->width[level], n = 4 * (size_t)t->width[level] * t->height[level];
+    size_t idx = 4 * ((size_t)x + (size_t)y * w);
+    for (int k = 0; k < 4; k++) c[k] = (idx + k < n ? t->texels[level][idx + k] : 0) / 255.0f;
+}
+
+/* lerpColor<float>, texture.cpp:14-17: (1 - ratio) * start + ratio * ends */
+static void lerp_color(float ratio, const float a[4], const float b[4], float out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = (1 - ratio) * a[k] + ratio * b[k];
+}
+
+/* sample_bilinear, texture.cpp:145-169 */
+static void sample_bilinear(const oracle_texture* t, float u, float v, int level, float out[4]) {
+    if (level < 0 || level >= (int)t->nlevels) { out[0] = 1; out[1] = 0; out[2] = 1; out[3] = 1; return; }
+    float wf = (float)t->width[level], hf = (float)t->height[level];
+    float su = clamp_f(u, 0.0f, 0.99999f) * wf;
+    float sv = clamp_f(v, 0.0f, 0.99999f) * hf;
+    float u0 = floorf(su) + 0.5f, v0 = floorf(sv) + 0.5f, u1, v1, tmp;
+    if (su - (int)su < 0.5f) { u1 = clamp_f(u0 - 1, 0.0f, wf); tmp = u1; u1 = u0; u0 = tmp; }
+    else { u1 = clamp_f(u0 + 1, 0.0f, wf); }
+    if (sv - (int)sv < 0.5f) { v1 = clamp_f(v0 - 1, 0.0f, hf); tmp = v1; v1 = v0; v0 = tmp; }
+    else { v1 = clamp_f(v0 + 1, 0.0f, hf); }
+    float c00[4], c10[4], c01[4], c11[4], h1[4], h2[4];
+    get_texel(t, level, (int)u0, (int)v0, c00);
+    get_texel(t, level, (int)u1, (int)v0, c10);
+    get_texel(t, level, (int)u0, (int)v1, c01);
+    get_texel(t, level, (int)u1, (int)v1, c11);
+    lerp_color((su - u0) / (u1 - u0), c00, c10, h1);
+    lerp_color((su - u0) / (u1 - u0), c01, c11, h2);
+    lerp_color((sv - v0) / (v1 - v0), h1, h2, out);
+}
+
+/* The mip level arithmetic of sample_trilinear (texture.cpp:171-193), which depends on the image only:
+ * mode 0 magenta, 1 bilinear at `low`, 2 lerp(frac, bilinear(low), bilinear(low + 1)). */
+void srt_oracle_trilinear_level(uint32_t tex_w, uint32_t tex_h, uint32_t nlevels, float u_scale, float v_scale,
+                                int* mode, int* low, float* frac) {
+    double ax = (double)((float)tex_w / u_scale), bx = (double)((float)tex_h / u_scale);
+    double ay = (double)((float)tex_w / v_scale), by = (double)((float)tex_h / v_scale);
+    float lsx = (float)(pow(ax, 2) + pow(bx, 2));
+    float lsy = (float)(pow(ay, 2) + pow(by, 2));
+    float level = log2f(sqrtf(max_f(lsx, lsy)));
+    if (level < 0) level = 0.0f;
+    *low = 0; *frac = 0.0f;
+    if (level >= (float)nlevels) { *mode = 0; return; }   /* also taken for +inf; NaN falls through as in the reference */
+    int lo = (int)floorf(level), hi = lo + 1;
+    if (hi >= (int)nlevels) { *mode = 1; *low = (int)nlevels - 1; return; }
+    *mode = 2; *low = lo; *frac = level - (int)level;
+}
+
+/* sample_trilinear, texture.cpp:171-193 */
+static void sample_trilinear(const oracle_texture* t, float u, float v, float u_scale, float v_scale, float out[4]) {
+    int mode, low; float frac;
+    srt_oracle_trilinear_level(t->width[0], t->height[0], t->nlevels, u_scale, v_scale, &mode, &low, &frac);
+    if (mode == 0) { out[0] = 1; out[1] = 0; out[2] = 1; out[3] = 1; return; }
+    if (mode == 1) { sample_bilinear(t, u, v, low, out); return; }
+    float a[4], b[4];
+    sample_bilinear(t, u, v, low, a);
+    sample_bilinear(t, u, v, low + 1, b);
+    lerp_color(frac, a, b, out);
+}
+
+/* rasterize_image, software_renderer.cpp:540-570.  Returns -1 if the float loops would not terminate. */
+static int rasterize_image(oracle_raster* o, float x0, float y0, float x1, float y1, const oracle_texture* t) {
+    float uscale = x1 - x0, vscale = y1 - y0;
+    x0 *= (float)o->sr; x1 *= (float)o->sr; y0 *= (float)o->sr; y1 *= (float)o->sr;
+    uint64_t guard = 0;
+    for (float x = x0; x <= x1; x++) {
+        if (++guard > (1u << 26) || x + 1 == x) return -1;
+        for (float y = y0; y <= y1; y++) {
+            if (y + 1 == y) return -1;
+            int sx = to_int((double)x), sy = to_int((double)y);
+            if (sx < 0 || (uint32_t)sx >= o->ssw || sy < 0 || (uint32_t)sy >= o->ssh) continue; /* fill_sample rejects */
+            float u = (float)((x + 0.5 - x0) / (x1 - x0));
+            float v = (float)((y + 0.5 - y0) / (y1 - y0));
+            float c[4];
+            sample_trilinear(t, u, v, uscale, vscale, c);
+            o->img += (uint64_t)fill_sample(o, sx, sy, c);
+        }
+    }
+    return 0;
+}
+
+/* Sampler2DImp::generate_mips(tex, 0), texture.cpp:53-120: level sizes and the 2x2 box filter.
+ * in: level 0 (w0 x h0 RGBA8).  out_w/out_h: SRT_MAX_MIP_LEVELS entries; out_blob: every level back to back
+ * (level 0 first), capacity blob_cap bytes.  Returns the number of levels, or -1. */
+int srt_oracle_generate_mips(const uint8_t* level0, uint32_t w0, uint32_t h0, uint32_t* out_w, uint32_t* out_h,
+                             uint8_t* out_blob, uint64_t blob_cap) {
+    if (!level0 || !w0 || !h0) return -1;
+    int base = (int)(w0 > h0 ? w0 : h0);
+    int sub = (int)(log2f((float)base));
+    if (sub > SRT_MAX_MIP_LEVELS - 1) sub = SRT_MAX_MIP_LEVELS - 1;
+    uint64_t off = 0;
+    int w = (int)w0, h = (int)h0;
+    out_w[0] = w0; out_h[0] = h0;
+    if (4ull * w0 * h0 > blob_cap) return -1;
+    memcpy(out_blob, level0, 4ull * w0 * h0);
+    const uint8_t* prev = out_blob;
+    int pw = w, ph = h;
+    off = 4ull * w0 * h0;
+    for (int i = 1; i <= sub; i++) {
+        w = w / 2 > 1 ? w / 2 : 1;
+        h = h / 2 > 1 ? h / 2 : 1;
+        out_w[i] = (uint32_t)w; out_h[i] = (uint32_t)h;
+        if (off + 4ull * w * h > blob_cap) return -1;
+        uint8_t* cur = out_blob + off;
+        size_t pn = 4 * (size_t)pw * ph;
+        for (int x = 0; x < w; x++) {
+            for (int y = 0; y < h; y++) {
+                float sum[4] = {0, 0, 0, 0};
+                for (int m = 0; m < 2; m++) {
+                    for (int n = 0; n < 2; n++) {
+                        size_t idx = 4 * ((size_t)(2 * x + m) + (size_t)(2 * y + n) * pw);
+                        for (int k = 0; k < 4; k++) sum[k] += (idx + k < pn ? prev[idx + k] : 0) / 255.0f;
+                    }
+                }
+                for (int k = 0; k < 4; k++) {
+                    sum[k] *= 0.25f;
+                    cur[4 * (x + y * w) + k] = (uint8_t)(255.f * max_f(0.0f, min_f(1.0f, sum[k])));  /* float_to_uint8 */
+                }
+            }
+        }
+        prev = cur; pw = w; ph = h;
+        off += 4ull * w * h;
+    }
+    return sub + 1;
+}
+
 /* resolve, software_renderer.cpp:573-622. */
 static void resolve(const oracle_raster* o, uint8_t* target) {
     const size_t sr = o->sr;
@@ -143,12 +286,16 @@ static void resolve(const oracle_raster* o, uint8_t* target) {
 
 /*
  * One frame: clear_target (software_renderer.h:93-98) -> the ordered rasterize_* calls -> resolve.
+ * Textures (for SRT_PRIM_IMAGE records, whose `reserved` field is the texture index): ntex mip chains described
+ * by tex_nlevels[ntex] and, concatenated over the textures, level_w / level_h / level_off (byte offsets into blob).
  * counts (optional) receives {tests, tests_in_target, fragments, point_samples}.
  * samples_out (optional) receives the float supersample buffer as it stands before resolve.
  * Returns 0, or -1 on bad arguments / allocation failure.
  */
-int srt_oracle_raster_frame(const srt_prim* prims, size_t n, uint32_t w, uint32_t h, uint32_t sr,
-                            uint8_t* rgba_out, float* samples_out, uint64_t counts[4]) {
+int srt_oracle_raster_frame_tex(const srt_prim* prims, size_t n, uint32_t w, uint32_t h, uint32_t sr, uint32_t ntex,
+                                const uint32_t* tex_nlevels, const uint32_t* level_w, const uint32_t* level_h,
+                                const uint64_t* level_off, const uint8_t* blob, uint8_t* rgba_out, float* samples_out,
+                                uint64_t counts[4]) {
     if (!w || !h || !sr || !rgba_out || (n && !prims)) return -1;
     oracle_raster o;
     memset(&o, 0, sizeof o);
@@ -156,19 +303,38 @@ int srt_oracle_raster_frame(const srt_prim* prims, size_t n, uint32_t w, uint32_
     o.ssw = w * sr; o.ssh = h * sr;
     size_t nfloats = 4 * (size_t)o.ssw * o.ssh;
     o.ss = (float*)malloc(nfloats * sizeof(float));
-    if (!o.ss) return -1;
+    oracle_texture* tex = ntex ? (oracle_texture*)calloc(ntex, sizeof(oracle_texture)) : NULL;
+    if (!o.ss || (ntex && !tex)) { free(o.ss); free(tex); return -1; }
+    for (uint32_t t = 0, l = 0; t < ntex; t++) {
+        if (tex_nlevels[t] == 0 || tex_nlevels[t] > SRT_MAX_MIP_LEVELS) { free(o.ss); free(tex); return -1; }
+        tex[t].nlevels = tex_nlevels[t];
+        for (uint32_t k = 0; k < tex_nlevels[t]; k++, l++) {
+            tex[t].width[k] = level_w[l]; tex[t].height[k] = level_h[l]; tex[t].texels[k] = blob + level_off[l];
+        }
+    }
     memset(rgba_out, 255, 4 * (size_t)w * h);
     for (size_t i = 0; i < nfloats; i++) o.ss[i] = 255.0f;
 
-    for (size_t i = 0; i < n; i++) {
+    int rc = 0;
+    for (size_t i = 0; i < n && rc == 0; i++) {
         const srt_prim* p = &prims[i];
         if (p->kind == SRT_PRIM_TRIANGLE) rasterize_triangle(&o, p->v.tri, p->rgba);
         else if (p->kind == SRT_PRIM_POINT) rasterize_point(&o, p->v.point[0], p->v.point[1], p->rgba);
-        else { free(o.ss); return -1; }
+        else if (p->kind == SRT_PRIM_IMAGE && p->reserved < ntex)
+            rc = rasterize_image(&o, p->v.tri[0], p->v.tri[1], p->v.tri[2], p->v.tri[3], &tex[p->reserved]);
+        else rc = -1;
     }
-    if (samples_out) memcpy(samples_out, o.ss, nfloats * sizeof(float));
-    resolve(&o, rgba_out);
-    if (counts) { counts[0] = o.tests; counts[1] = o.tests_in; counts[2] = o.frags; counts[3] = o.pts; }
+    if (rc == 0) {
+        if (samples_out) memcpy(samples_out, o.ss, nfloats * sizeof(float));
+        resolve(&o, rgba_out);
+        if (counts) { counts[0] = o.tests; counts[1] = o.tests_in; counts[2] = o.frags; counts[3] = o.pts; }
+    }
     free(o.ss);
-    return 0;
+    free(tex);
+    return rc;
+}
+
+int srt_oracle_raster_frame(const srt_prim* prims, size_t n, uint32_t w, uint32_t h, uint32_t sr,
+                            uint8_t* rgba_out, float* samples_out, uint64_t counts[4]) {
+    return srt_oracle_raster_frame_tex(prims, n, w, h, sr, 0, NULL, NULL, NULL, NULL, NULL, rgba_out, samples_out, counts);
 }

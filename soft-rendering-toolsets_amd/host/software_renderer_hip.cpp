@@ -59,6 +59,17 @@ void SoftwareRendererHIP::draw_svg(SVG& svg) {
   }
   clear_target();
   const std::vector<srt_prim>& stream = builder_.build(svg, svg_2_screen, sample_rate);
+  // <image> textures: the mip chains DrawSVG::regenerate_mipmap built with the application's sampler
+  die_on(srt_raster_clear_textures(ctx_), "srt_raster_clear_textures");
+  for (const Texture* tex : builder_.textures()) {
+    uint32_t w[SRT_MAX_MIP_LEVELS], h[SRT_MAX_MIP_LEVELS], id = 0;
+    const uint8_t* lv[SRT_MAX_MIP_LEVELS];
+    const size_t n = tex->mipmap.size() < (size_t)SRT_MAX_MIP_LEVELS ? tex->mipmap.size() : (size_t)SRT_MAX_MIP_LEVELS;
+    for (size_t k = 0; k < n; k++) {
+      w[k] = (uint32_t)tex->mipmap[k].width; h[k] = (uint32_t)tex->mipmap[k].height; lv[k] = tex->mipmap[k].texels.data();
+    }
+    die_on(srt_raster_add_texture(ctx_, (uint32_t)n, w, h, lv, &id), "srt_raster_add_texture");
+  }
   die_on(srt_raster_submit(ctx_, stream.data(), stream.size()), "srt_raster_submit");
   die_on(srt_raster_resolve(ctx_, render_target), "srt_raster_resolve");
 }

@@ -10,7 +10,8 @@
 // Split of work:
 //   host  : element walk, transform stack, ear-clip triangulation (the reference's own
 //           triangulate()), Xiaolin-Wu line decomposition into rasterize_point blocks (svg_stream.cpp)
-//   device: rasterize_triangle + inside_triangle + fill_sample + rasterize_point + resolve
+//   device: rasterize_triangle + inside_triangle + fill_sample + rasterize_point + rasterize_image
+//           (Sampler2DImp::sample_trilinear over the application's mip chains) + resolve
 #ifndef SRT_SOFTWARE_RENDERER_HIP_H
 #define SRT_SOFTWARE_RENDERER_HIP_H
 
@@ -33,9 +34,6 @@ class SoftwareRendererHIP : public SoftwareRenderer {
 
   // Mirrors SoftwareRendererImp::clear_target (software_renderer.h:93-98).
   void clear_target();
-
-  // Number of <image> elements skipped by the last draw_svg (unsupported on this path).
-  size_t skipped_images() const { return builder_.skipped_images(); }
 
  private:
   srt_raster* ctx_;

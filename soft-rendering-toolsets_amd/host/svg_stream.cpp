@@ -27,7 +27,7 @@ inline float wu_rfrac(float v) { return 1 - wu_frac(v); }
 
 const std::vector<srt_prim>& SvgStreamBuilder::build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate) {
   stream_.clear();
-  skipped_images_ = 0;
+  textures_.clear();
   sample_rate_ = sample_rate;
   transformation = svg_2_screen;
 
@@ -133,12 +133,12 @@ void SvgStreamBuilder::walk(SVGElement* e) {
       for (size_t i = 0; i < g.elements.size(); ++i) walk(g.elements[i]);
     } break;
 
-    case IMAGE:
-      // rasterize_image + Sampler2D are outside this path. No CPU
-      // fallback exists on purpose: say so loudly and skip the element.
-      if (skipped_images_++ == 0)
-        std::fprintf(stderr, "[SvgStreamBuilder] <image> elements are not supported on the HIP path; skipped\n");
-      break;
+    case IMAGE: {  // draw_image (cpp:249-256): the double corners narrow to rasterize_image's float parameters
+      Image& im = static_cast<Image&>(*e);
+      Vector2D p0 = transform(im.position);
+      Vector2D p1 = transform(im.position + im.dimension);
+      emit_image(p0.x, p0.y, p1.x, p1.y, im.tex);
+    } break;
 
     case ELLIPSE:  // draw_ellipse is empty in the reference (cpp:243-247)
     default:
@@ -172,6 +172,18 @@ void SvgStreamBuilder::emit_point(double x, double y, const Color& c) {
 
 // Xiaolin Wu anti-aliased line -> ordered rasterize_point calls (cpp:365-454). All math in
 // float, as in the reference; the stroke alpha is REPLACED by the Wu coverage, not scaled.
+void SvgStreamBuilder::emit_image(float x0, float y0, float x1, float y1, const Texture& tex) {
+  srt_prim p;
+  std::memset(&p, 0, sizeof p);
+  p.kind = SRT_PRIM_IMAGE;
+  size_t id = 0;
+  while (id < textures_.size() && textures_[id] != &tex) id++;
+  if (id == textures_.size()) textures_.push_back(&tex);
+  p.reserved = (uint32_t)id;
+  p.v.tri[0] = x0; p.v.tri[1] = y0; p.v.tri[2] = x1; p.v.tri[3] = y1;
+  stream_.push_back(p);
+}
+
 void SvgStreamBuilder::emit_line(float x0, float y0, float x1, float y1, Color color) {
   const bool steep = std::abs(x1 - x0) < std::abs(y1 - y0);
   if (steep) { std::swap(x0, y0); std::swap(x1, y1); }

@@ -15,7 +15,7 @@ namespace CMU462 {
 
 class SvgStreamBuilder : public SVGRenderer {
  public:
-  SvgStreamBuilder() : sample_rate_(1), skipped_images_(0) {}
+  SvgStreamBuilder() : sample_rate_(1) {}
 
   // SVGRenderer interface: same as build().
   void draw_svg(SVG& svg) { build(svg, transformation, sample_rate_); }
@@ -25,18 +25,21 @@ class SvgStreamBuilder : public SVGRenderer {
   const std::vector<srt_prim>& build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate);
 
   const std::vector<srt_prim>& stream() const { return stream_; }
-  // Number of <image> elements skipped by the last build (unsupported on this path).
-  size_t skipped_images() const { return skipped_images_; }
+  // Textures of the <image> elements met by the last build, in walk order: an SRT_PRIM_IMAGE record's `reserved`
+  // field indexes this list.  The mip chains are the application's (DrawSVG::regenerate_mipmap ->
+  // Sampler2D::generate_mips); the caller uploads them with srt_raster_add_texture before submitting the stream.
+  const std::vector<const Texture*>& textures() const { return textures_; }
 
  private:
   void walk(SVGElement* element);
   void emit_triangle(float x0, float y0, float x1, float y1, float x2, float y2, const Color& c);
   void emit_point(double x, double y, const Color& c);
   void emit_line(float x0, float y0, float x1, float y1, Color c);
+  void emit_image(float x0, float y0, float x1, float y1, const Texture& tex);
 
   size_t sample_rate_;
   std::vector<srt_prim> stream_;
-  size_t skipped_images_;
+  std::vector<const Texture*> textures_;
 };
 
 }  // namespace CMU462

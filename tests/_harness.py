@@ -60,28 +60,126 @@ def ref_raster():
     return _ref_raster
 
 
-def oracle_raster_frame(prims, w, h, sr, want_samples=False):
+class Textures:
+    """Mip chains in the flat form the checkers take: per texture the number of levels; per level (concatenated
+    over the textures) width, height and byte offset into one RGBA8 blob."""
+
+    def __init__(self, nlevels=(), level_w=(), level_h=(), level_off=(), blob=b""):
+        self.nlevels = np.ascontiguousarray(nlevels, np.uint32)
+        self.level_w = np.ascontiguousarray(level_w, np.uint32)
+        self.level_h = np.ascontiguousarray(level_h, np.uint32)
+        self.level_off = np.ascontiguousarray(level_off, np.uint64)
+        self.blob = np.ascontiguousarray(np.frombuffer(bytes(blob), np.uint8) if not isinstance(blob, np.ndarray) else blob, np.uint8)
+
+    def __len__(self):
+        return len(self.nlevels)
+
+    def texture(self, t):
+        """[(w, h, texels[h, w, 4])] for texture t."""
+        l0 = int(self.nlevels[:t].sum())
+        out = []
+        for l in range(l0, l0 + int(self.nlevels[t])):
+            w, h, off = int(self.level_w[l]), int(self.level_h[l]), int(self.level_off[l])
+            out.append((w, h, self.blob[off:off + 4 * w * h].reshape(h, w, 4)))
+        return out
+
+    def args(self):
+        return (len(self.nlevels), P(self.nlevels) if len(self.nlevels) else None, P(self.level_w) if len(self.level_w) else None,
+                P(self.level_h) if len(self.level_h) else None, P(self.level_off) if len(self.level_off) else None,
+                P(self.blob) if len(self.blob) else None)
+
+    def to_npz(self):
+        return dict(tex_nlevels=self.nlevels, tex_level_w=self.level_w, tex_level_h=self.level_h, tex_level_off=self.level_off,
+                    tex_blob=self.blob)
+
+    @staticmethod
+    def from_npz(g):
+        if "tex_nlevels" not in g:
+            return Textures()
+        return Textures(g["tex_nlevels"], g["tex_level_w"], g["tex_level_h"], g["tex_level_off"], g["tex_blob"])
+
+    @staticmethod
+    def from_level0(images, mips_fn):
+        """images: list of uint8 [h, w, 4]; mips_fn(level0) -> [(w, h, texels)] (oracle_generate_mips / ref_generate_mips)."""
+        nl, lw, lh, lo, blob = [], [], [], [], []
+        off = 0
+        for im in images:
+            chain = mips_fn(im)
+            nl.append(len(chain))
+            for w, h, tx in chain:
+                lw.append(w); lh.append(h); lo.append(off)
+                blob.append(np.ascontiguousarray(tx, np.uint8).reshape(-1))
+                off += 4 * w * h
+        return Textures(nl, lw, lh, lo, np.concatenate(blob) if blob else np.zeros(0, np.uint8))
+
+
+def _mips(fn, level0):
+    level0 = np.ascontiguousarray(level0, np.uint8)
+    h, w = level0.shape[:2]
+    lw = np.zeros(16, np.uint32)
+    lh = np.zeros(16, np.uint32)
+    blob = np.zeros(2 * 4 * w * h + 64, np.uint8)
+    n = fn(P(level0), w, h, P(lw), P(lh), P(blob), ctypes.c_uint64(len(blob)))
+    assert n > 0
+    out, off = [], 0
+    for k in range(n):
+        out.append((int(lw[k]), int(lh[k]), blob[off:off + 4 * int(lw[k]) * int(lh[k])].reshape(int(lh[k]), int(lw[k]), 4).copy()))
+        off += 4 * int(lw[k]) * int(lh[k])
+    return out
+
+
+def oracle_generate_mips(level0):
+    """Sampler2DImp::generate_mips as restated in oracle/raster_oracle.c: [(w, h, texels[h, w, 4])]."""
+    return _mips(oracle().srt_oracle_generate_mips, level0)
+
+
+def ref_generate_mips(level0):
+    lib = ref_raster()
+    lib.ref_raster_generate_mips.restype = ctypes.c_long
+    return _mips(lib.ref_raster_generate_mips, level0)
+
+
+def oracle_raster_frame(prims, w, h, sr, want_samples=False, textures=None):
     """Run oracle/raster_oracle.c on an ordered stream. Returns (rgba8, samples|None, counts)."""
     prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
     rgba = np.zeros((h, w, 4), np.uint8)
     ss = np.zeros((h * sr, w * sr, 4), np.float32) if want_samples else None
     counts = np.zeros(4, np.uint64)
-    rc = oracle().srt_oracle_raster_frame(
-        P(prims), ctypes.c_size_t(len(prims)), w, h, sr, P(rgba), P(ss) if want_samples else None, P(counts)
+    tex = textures or Textures()
+    rc = oracle().srt_oracle_raster_frame_tex(
+        P(prims), ctypes.c_size_t(len(prims)), w, h, sr, *tex.args(), P(rgba), P(ss) if want_samples else None, P(counts)
     )
     assert rc == 0
     return rgba, ss, counts
 
 
-def ref_raster_prims(prims, w, h, sr, want_samples=False):
+def ref_raster_prims(prims, w, h, sr, want_samples=False, textures=None):
     prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
     rgba = np.zeros((h, w, 4), np.uint8)
     ss = np.zeros((h * sr, w * sr, 4), np.float32) if want_samples else None
-    rc = ref_raster().ref_raster_prims(
-        P(prims), ctypes.c_size_t(len(prims)), w, h, sr, P(rgba), P(ss) if want_samples else None
+    tex = textures or Textures()
+    rc = ref_raster().ref_raster_prims_tex(
+        P(prims), ctypes.c_size_t(len(prims)), w, h, sr, *tex.args(), P(rgba), P(ss) if want_samples else None
     )
     assert rc == 0
     return rgba, ss
+
+
+def ref_svg_textures(path, w, h, sr):
+    """Textures (reference mip chains) of the <image> elements of an SVG, in stream order."""
+    lib = ref_raster()
+    lib.ref_raster_svg_textures.restype = ctypes.c_long
+    nl = np.zeros(16, np.uint32)
+    lw = np.zeros(16 * 14, np.uint32)
+    lh = np.zeros(16 * 14, np.uint32)
+    lo = np.zeros(16 * 14, np.uint64)
+    blob = np.zeros(64 << 20, np.uint8)
+    n = lib.ref_raster_svg_textures(path if isinstance(path, bytes) else path.encode(), w, h, sr, 16, P(nl), P(lw), P(lh), P(lo), P(blob),
+                                    ctypes.c_uint64(len(blob)))
+    assert n >= 0, n
+    nlev = int(nl[:n].sum())
+    size = int(lo[nlev - 1] + 4 * int(lw[nlev - 1]) * int(lh[nlev - 1])) if nlev else 0
+    return Textures(nl[:n], lw[:nlev], lh[:nlev], lo[:nlev], blob[:size].copy())
 
 
 def sha(a):
