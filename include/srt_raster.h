@@ -11,6 +11,9 @@
  *                              rasterize_triangle  src/software_renderer.cpp:456-516 (+ inside_triangle :519-538,
  *                                                   fill_sample :634-658)
  *                              rasterize_point     src/software_renderer.cpp:272-301
+ *                              rasterize_image     src/software_renderer.cpp:540-570 (+ Sampler2DImp, src/texture.cpp:145-193)
+ *   srt_raster_add_texture  <- the CMU462::Texture of an <image> element after Sampler2D::generate_mips
+ *                              (DrawSVG::regenerate_mipmap, src/drawsvg.cpp:462-474)
  *   srt_raster_resolve      <- SoftwareRendererImp::resolve            src/software_renderer.cpp:573-622
  *
  * The host element walk (draw_svg / draw_element / transform stack / Xiaolin-Wu line
@@ -89,6 +92,16 @@ int srt_raster_clear(srt_raster* r);
 
 /* Append `n` primitives (host memory) to the frame's ordered stream. May be called repeatedly. */
 int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n);
+
+/* Textures for SRT_PRIM_IMAGE records (CMU462::Texture, D/src/texture.h:24-28): a mip chain of 1..14 RGBA8
+ * levels as Sampler2D::generate_mips left it (level k is widths[k] x heights[k], row-major, 4 bytes per texel;
+ * the library copies the texels).  The id (0, 1, ... in call order) goes into the record's `reserved` field.
+ * Textures stay loaded across frames until srt_raster_clear_textures.  Sampling is the reference's
+ * Sampler2DImp::sample_trilinear (texture.cpp:171-193); texels it indexes past the end of a level (undefined in
+ * the reference: column `width` / row `height` at the right / bottom border) read as zero. */
+int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widths, const uint32_t* heights,
+                           const uint8_t* const* level_texels, uint32_t* id_out);
+int srt_raster_clear_textures(srt_raster* r);
 
 /* Rasterize the pending stream in order, box-filter resolve, and write width*height RGBA8
  * (row 0 = top, row-major) into host memory `rgba8_out`. Synchronous: the buffer is complete on return. */

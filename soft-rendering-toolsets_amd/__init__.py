@@ -37,6 +37,7 @@ PRIM_DTYPE = np.dtype(
 )
 PRIM_TRIANGLE = 1
 PRIM_POINT = 2
+PRIM_IMAGE = 3
 
 
 class SrtError(RuntimeError):
@@ -108,6 +109,18 @@ def _check(lib, status: int) -> None:
 
 def make_prims(n: int) -> np.ndarray:
     return np.zeros(n, dtype=PRIM_DTYPE)
+
+
+def image_prims(rects: np.ndarray, tex_ids) -> np.ndarray:
+    """rects: (n,4) float32 x0 y0 x1 y1 (the float parameters of rasterize_image); tex_ids: texture id per image."""
+    rects = np.ascontiguousarray(rects, dtype=np.float32).reshape(-1, 4)
+    p = make_prims(len(rects))
+    p["kind"] = PRIM_IMAGE
+    p["reserved"] = np.asarray(tex_ids, dtype=np.uint32)
+    v = np.zeros((len(rects), 6), np.float32)
+    v[:, :4] = rects
+    p["v"] = v.view(np.float64).reshape(-1, 3)
+    return p
 
 
 def triangle_prims(xy: np.ndarray, rgba: np.ndarray) -> np.ndarray:
@@ -189,6 +202,23 @@ class SoftwareRenderer:
     def submit(self, prims: np.ndarray) -> None:
         prims = np.ascontiguousarray(prims, dtype=PRIM_DTYPE)
         _check(self._lib, self._lib.srt_raster_submit(self._ctx, prims.ctypes.data_as(c_void_p), len(prims)))
+
+    def add_texture(self, levels) -> int:
+        """levels: the mip chain [(w, h, texels uint8 [h, w, 4]), ...] (level 0 first) as Sampler2D::generate_mips
+        left it.  Returns the texture id that goes into an image primitive's `reserved` field."""
+        n = len(levels)
+        ws = (ctypes.c_uint32 * n)(*[int(l[0]) for l in levels])
+        hs = (ctypes.c_uint32 * n)(*[int(l[1]) for l in levels])
+        keep = [np.ascontiguousarray(l[2], dtype=np.uint8) for l in levels]
+        for (w, h, _), k in zip(levels, keep):
+            assert k.size == 4 * int(w) * int(h)
+        ptrs = (c_void_p * n)(*[k.ctypes.data for k in keep])
+        tid = ctypes.c_uint32()
+        _check(self._lib, self._lib.srt_raster_add_texture(self._ctx, n, ws, hs, ptrs, ctypes.byref(tid)))
+        return tid.value
+
+    def clear_textures(self) -> None:
+        _check(self._lib, self._lib.srt_raster_clear_textures(self._ctx))
 
     def resolve(self) -> np.ndarray:
         out = self.render_target

@@ -6,6 +6,8 @@
 //   inside_triangle     software_renderer.cpp:519-538   fp64 edge functions rounded to fp32, fp32 sign products
 //   fill_sample         software_renderer.cpp:634-658   non-premultiplied "over" on a float RGBA sample in [0,255]
 //   rasterize_point     software_renderer.cpp:272-301   sr x sr block, double -> int truncation
+//   rasterize_image     software_renderer.cpp:540-570   float x/y loops, fp64 u/v, Sampler2DImp::sample_trilinear
+//   sample_bilinear     texture.cpp:145-169             4 texels of one mip level, lerpColor in fp32
 //   resolve             software_renderer.cpp:573-622   fp32 box sum (x-offset outer, y-offset inner), /sr^2, (uint8_t)
 //
 // Execution model: one wavefront (64 lanes) owns one tile of at most 32x32 samples.  The supersample
@@ -20,8 +22,10 @@
 // sample is bit-identical to the CPU reference.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <vector>
 
@@ -42,6 +46,24 @@ struct RasterParams {
   uint32_t coarse_tiles;         // a coarse bin is coarse_tiles x coarse_tiles tiles
   uint32_t coarse_x, coarse_y;   // coarse grid
   uint32_t list_stride;          // entries reserved per coarse bin (= nprims)
+};
+
+// Everything about one SRT_PRIM_IMAGE record that does not depend on the sample, prepared on the host at upload
+// (upload_stream): the parameters after rasterize_image's `x0 *= sample_rate` (float *= size_t), the mip level
+// arithmetic of sample_trilinear (it depends on the image extent only and uses the host's log2f, as the reference
+// does), the two mip levels involved, and the values the reference's float loops `for (float x = x0; x <= x1; x++)`
+// take: for every sample column / row of the target the (at most two) loop values that fill_sample's double->int
+// conversion sends there, in loop order (NaN = none).  Two values per column only happen at column 0, where
+// truncation toward zero folds (-1, 0) and [0, 1) together.
+struct ImageAux {
+  float x0s, y0s, x1s, y1s;
+  int32_t mode;              // 0: magenta (level >= mipmap.size()), 1: bilinear at `low`, 2: lerp(frac, low, low + 1)
+  int32_t low;
+  float frac;
+  uint32_t pad;
+  uint32_t off[2], w[2], h[2];  // byte offset into the texel blob / size of levels low and low + 1
+  uint32_t xtab, ytab;          // float offsets into the table buffer: [xtab, xtab + ssw) first values, then the second
+  int32_t bx0, by0, bx1, by1;   // inclusive sample bbox of the filled columns / rows (bx0 > bx1: touches nothing)
 };
 
 // stats slots (unsigned long long each)
@@ -66,8 +88,8 @@ __device__ __forceinline__ float4 blend_over(float4 s, float r, float g, float b
 // Pass 1: per-primitive sample-space bounding box clipped to the target, int4 {x0,y0,x1,y1}
 // (inclusive; x0 > x1 marks "touches nothing").  Also the reference's own (unclipped) test count.
 // ---------------------------------------------------------------------------------------------
-__global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims, int4* __restrict__ bbox,
-                             unsigned long long* __restrict__ stats) {
+__global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims, const ImageAux* __restrict__ aux,
+                             int4* __restrict__ bbox, unsigned long long* __restrict__ stats) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.nprims) return;
   const srt_prim p = prims[i];
@@ -96,6 +118,11 @@ __global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims,
     ok = (fx > -lim) && (fx < lim) && (fy > -lim) && (fy < lim);
     lox = trunc(fx); hix = trunc(fx + (double)(P.sr - 1));
     loy = trunc(fy); hiy = trunc(fy + (double)(P.sr - 1));
+  }
+  if (p.kind == SRT_PRIM_IMAGE) {   // `reserved` of the device copy = index of the record's ImageAux
+    const ImageAux a = aux[p.reserved];
+    bbox[i] = make_int4(a.bx0, a.by0, a.bx1, a.by1);
+    return;
   }
   if (ok) {
     const double wx = (double)(P.ssw - 1), wy = (double)(P.ssh - 1);
@@ -144,6 +171,53 @@ __global__ __launch_bounds__(256) void raster_coarse_bin(RasterParams P, const i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Texture sampling (texture.cpp).  Colors are float4 {r, g, b, a}.
+// ---------------------------------------------------------------------------------------------
+// CMU462::clamp<float> = std::min(std::max(x, lo), hi)
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return std_min(std_max(x, lo), hi); }
+
+// GetColorFromTexture (texture.cpp:19-25): index 4 * (x + y * width) in size_t arithmetic; texels past the end of
+// the level (undefined in the reference: one column / row past the level at the right / bottom border) read as zero.
+__device__ __forceinline__ float4 get_texel(const uint8_t* __restrict__ level, uint32_t w, uint32_t h, int x, int y) {
+  const unsigned long long idx = 4ull * ((unsigned long long)(long long)x + (unsigned long long)(long long)y * w);
+  uint32_t t = 0;
+  if (idx + 3 < 4ull * w * h) t = *reinterpret_cast<const uint32_t*>(level + idx);
+  return make_float4((float)(t & 255u) / 255.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f,
+                     (float)(t >> 24) / 255.0f);
+}
+
+// lerpColor<float> (texture.cpp:14-17): (1 - ratio) * start + ratio * ends
+__device__ __forceinline__ float4 lerp_color(float ratio, float4 a, float4 b) {
+  const float om = 1 - ratio;
+  return make_float4(om * a.x + ratio * b.x, om * a.y + ratio * b.y, om * a.z + ratio * b.z, om * a.w + ratio * b.w);
+}
+
+// Sampler2DImp::sample_bilinear (texture.cpp:145-169) on one level.
+__device__ __forceinline__ float4 sample_bilinear(const uint8_t* __restrict__ level, uint32_t w, uint32_t h, float u, float v) {
+  const float wf = (float)w, hf = (float)h;
+  const float su = clampf(u, 0.0f, 0.99999f) * wf;
+  const float sv = clampf(v, 0.0f, 0.99999f) * hf;
+  float u0 = floorf(su) + 0.5f, v0 = floorf(sv) + 0.5f, u1, v1;
+  if (su - (float)(int)su < 0.5f) { u1 = u0; u0 = clampf(u0 - 1, 0.0f, wf); }   // clamp, then swap(u1, u0)
+  else { u1 = clampf(u0 + 1, 0.0f, wf); }
+  if (sv - (float)(int)sv < 0.5f) { v1 = v0; v0 = clampf(v0 - 1, 0.0f, hf); }
+  else { v1 = clampf(v0 + 1, 0.0f, hf); }
+  const float4 c00 = get_texel(level, w, h, (int)u0, (int)v0), c10 = get_texel(level, w, h, (int)u1, (int)v0);
+  const float4 c01 = get_texel(level, w, h, (int)u0, (int)v1), c11 = get_texel(level, w, h, (int)u1, (int)v1);
+  const float ru = (su - u0) / (u1 - u0), rv = (sv - v0) / (v1 - v0);
+  return lerp_color(rv, lerp_color(ru, c00, c10), lerp_color(ru, c01, c11));
+}
+
+// Sampler2DImp::sample_trilinear (texture.cpp:171-193) with the level arithmetic already done (ImageAux).
+__device__ __forceinline__ float4 sample_image(const ImageAux& A, const uint8_t* __restrict__ texels, float u, float v) {
+  if (A.mode == 0) return make_float4(1.0f, 0.0f, 1.0f, 1.0f);
+  const float4 lo = sample_bilinear(texels + A.off[0], A.w[0], A.h[0], u, v);
+  if (A.mode == 1) return lo;
+  const float4 hi = sample_bilinear(texels + A.off[1], A.w[1], A.h[1], u, v);
+  return lerp_color(A.frac, lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pass 2: one wave per tile.
 // ---------------------------------------------------------------------------------------------
 template <bool STATS>
@@ -151,6 +225,8 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
                                                      const uint32_t* __restrict__ counts,
+                                                     const ImageAux* __restrict__ aux, const float* __restrict__ tabs,
+                                                     const uint8_t* __restrict__ texels,
                                                      uint32_t* __restrict__ rgba_out,
                                                      float4* __restrict__ samples_out,
                                                      unsigned long long* __restrict__ stats) {
@@ -247,6 +323,31 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
             tile[si] = blend_over(tile[si], cr, cg, cb, one_minus_a);
           }
           if (STATS) n_frags += __popcll(__ballot(covered));
+        }
+      } else if (kind == SRT_PRIM_IMAGE) {
+        // rasterize_image: every (x, y) pair of the float loops whose truncation lands on this lane's sample, x outer
+        const ImageAux A = aux[__builtin_amdgcn_readlane(q0.y, b)];
+        const int sx = sx0 + lx;
+        const bool xin = (lx >= rx0) && (lx <= rx1);
+        float xv[2] = {std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN()};
+        if (xin) { xv[0] = tabs[A.xtab + sx]; xv[1] = tabs[A.xtab + P.ssw + sx]; }
+        const double xden = (double)(A.x1s - A.x0s), yden = (double)(A.y1s - A.y0s);
+        for (int row = ry0 + lrow; row <= ry1; row += 2) {
+          const int sy = sy0 + row;
+          const float yv[2] = {tabs[A.ytab + sy], tabs[A.ytab + P.ssh + sy]};
+          const int si = row * TS + lx;
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              if (xv[i] == xv[i] && yv[j] == yv[j]) {   // not NaN
+                const float u = (float)(((double)xv[i] + 0.5 - (double)A.x0s) / xden);
+                const float v = (float)(((double)yv[j] + 0.5 - (double)A.y0s) / yden);
+                const float4 c = sample_image(A, texels, u, v);
+                tile[si] = blend_over(tile[si], c.x, c.y, c.z, 1 - c.w);
+              }
+            }
+          }
         }
       } else {  // SRT_PRIM_POINT
         const uint32_t sr = P.sr;
@@ -347,6 +448,14 @@ struct srt_raster {
   float4* d_samples = nullptr;
   unsigned long long* d_stats = nullptr;
   bool resolved = false;
+  // textures (srt_raster_add_texture): host copies, then one device blob with 4-byte aligned levels
+  struct Tex { uint32_t nlevels; uint32_t w[SRT_MAX_MIP_LEVELS], h[SRT_MAX_MIP_LEVELS]; size_t off[SRT_MAX_MIP_LEVELS]; };
+  std::vector<Tex> textures;
+  std::vector<uint8_t> texel_blob;
+  bool tex_dirty = true;
+  uint8_t* d_texels = nullptr; size_t texels_cap = 0;
+  ImageAux* d_aux = nullptr; size_t aux_cap = 0;
+  float* d_tabs = nullptr; size_t tabs_cap = 0;
 };
 
 namespace {
@@ -363,7 +472,108 @@ int upload_stream(srt_raster* r) {
     SRT_HIP(hipMalloc(&r->d_bbox, cap * sizeof(int4)));
     r->d_cap = cap;
   }
-  if (n) SRT_HIP(hipMemcpyAsync(r->d_prims, r->pending.data(), n * sizeof(srt_prim), hipMemcpyHostToDevice, r->stream));
+  // SRT_PRIM_IMAGE records: per-image constants and loop-value tables (ImageAux); the device copy of the record
+  // carries the index of its ImageAux in `reserved`
+  std::vector<ImageAux> aux;
+  std::vector<float> tabs;
+  std::vector<std::pair<size_t, uint32_t>> patched;   // (record, original reserved)
+  const RasterParams& P = r->P;
+  const float qnan = std::numeric_limits<float>::quiet_NaN();
+  for (size_t i = 0; i < n; i++) {
+    srt_prim& p = r->pending[i];
+    if (p.kind != SRT_PRIM_IMAGE) continue;
+    if (p.reserved >= r->textures.size())
+      return srt::fail(SRT_ERR_INVALID, "primitive %zu refers to texture %u, %zu textures are loaded", i, p.reserved, r->textures.size());
+    const srt_raster::Tex& T = r->textures[p.reserved];
+    ImageAux A;
+    std::memset(&A, 0, sizeof A);
+    float x0 = p.v.tri[0], y0 = p.v.tri[1], x1 = p.v.tri[2], y1 = p.v.tri[3];
+    const float uscale = x1 - x0, vscale = y1 - y0;                // software_renderer.cpp:553
+    x0 *= (float)P.sr; x1 *= (float)P.sr; y0 *= (float)P.sr; y1 *= (float)P.sr;   // :556 (float *= size_t)
+    A.x0s = x0; A.y0s = y0; A.x1s = x1; A.y1s = y1;
+    {   // sample_trilinear's level (texture.cpp:179-192); float / double steps as the reference's expressions resolve
+      const double ax = (double)((float)T.w[0] / uscale), bx = (double)((float)T.h[0] / uscale);
+      const double ay = (double)((float)T.w[0] / vscale), by = (double)((float)T.h[0] / vscale);
+      const float lsx = (float)(std::pow(ax, 2) + std::pow(bx, 2));
+      const float lsy = (float)(std::pow(ay, 2) + std::pow(by, 2));
+      float level = log2f(std::sqrt(lsx < lsy ? lsy : lsx));       // std::max(a, b) = (a < b) ? b : a
+      if (level < 0) level = 0.0f;
+      if (level >= (float)T.nlevels) { A.mode = 0; }
+      else {
+        const int lo = (int)std::floor(level), hi = lo + 1;
+        if (hi >= (int)T.nlevels) { A.mode = 1; A.low = (int)T.nlevels - 1; }
+        else { A.mode = 2; A.low = lo; A.frac = level - (float)(int)level; }
+      }
+    }
+    for (int k = 0; k < 2; k++) {
+      const int lv = A.low + k < (int)T.nlevels ? A.low + k : A.low;
+      A.off[k] = (uint32_t)T.off[lv]; A.w[k] = T.w[lv]; A.h[k] = T.h[lv];
+    }
+    // the float loops of rasterize_image (:557-559), recorded per target column / row
+    A.xtab = (uint32_t)tabs.size();
+    tabs.resize(tabs.size() + 2 * (size_t)P.ssw, qnan);
+    A.ytab = (uint32_t)tabs.size();
+    tabs.resize(tabs.size() + 2 * (size_t)P.ssh, qnan);
+    if (tabs.size() > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "image tables exceed 2^32 entries");
+    A.bx0 = A.by0 = 1; A.bx1 = A.by1 = 0;
+    auto walk = [&](float lo, float hi, uint32_t extent, uint32_t tab, int32_t& b0, int32_t& b1) -> int {
+      bool any = false;
+      uint64_t guard = 0;
+      for (float x = lo; x <= hi; x++) {
+        if (x + 1 == x || ++guard > (1ull << 26)) return -1;       // the reference's loop would never end
+        if (!(x > -2147483648.0f && x < 2147483648.0f)) continue;  // (int)x is INT_MIN on x86: rejected by fill_sample
+        const int sx = (int)x;
+        if (sx < 0 || (uint32_t)sx >= extent) continue;
+        float* e = &tabs[tab + sx];
+        if (e[0] != e[0]) e[0] = x;
+        else if (e[extent] != e[extent]) e[extent] = x;
+        else return -2;
+        if (!any) { b0 = b1 = sx; any = true; }
+        b0 = sx < b0 ? sx : b0; b1 = sx > b1 ? sx : b1;
+      }
+      return any ? 1 : 0;
+    };
+    const int rx = walk(x0, x1, P.ssw, A.xtab, A.bx0, A.bx1);
+    const int ry = walk(y0, y1, P.ssh, A.ytab, A.by0, A.by1);
+    if (rx < 0 || ry < 0)
+      return srt::fail(SRT_ERR_UNSUPPORTED, "image primitive %zu: extent (%g, %g)-(%g, %g) samples is outside what the reference's float loops can walk",
+                       i, (double)x0, (double)y0, (double)x1, (double)y1);
+    if (rx == 0 || ry == 0) { A.bx0 = A.by0 = 1; A.bx1 = A.by1 = 0; }
+    patched.emplace_back(i, p.reserved);
+    p.reserved = (uint32_t)aux.size();
+    aux.push_back(A);
+  }
+  hipError_t up = hipSuccess;
+  if (n) up = hipMemcpy(r->d_prims, r->pending.data(), n * sizeof(srt_prim), hipMemcpyHostToDevice);
+  for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;   // the host copy keeps texture ids
+  SRT_HIP(up);
+  if (!aux.empty()) {
+    if (aux.size() > r->aux_cap) {
+      if (r->d_aux) SRT_HIP(hipFree(r->d_aux));
+      r->d_aux = nullptr;
+      SRT_HIP(hipMalloc(&r->d_aux, aux.size() * sizeof(ImageAux)));
+      r->aux_cap = aux.size();
+    }
+    if (tabs.size() > r->tabs_cap) {
+      if (r->d_tabs) SRT_HIP(hipFree(r->d_tabs));
+      r->d_tabs = nullptr;
+      SRT_HIP(hipMalloc(&r->d_tabs, tabs.size() * sizeof(float)));
+      r->tabs_cap = tabs.size();
+    }
+    SRT_HIP(hipMemcpy(r->d_aux, aux.data(), aux.size() * sizeof(ImageAux), hipMemcpyHostToDevice));
+    SRT_HIP(hipMemcpy(r->d_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (r->tex_dirty) {
+      const size_t nb = r->texel_blob.size() ? r->texel_blob.size() : 4;
+      if (nb > r->texels_cap) {
+        if (r->d_texels) SRT_HIP(hipFree(r->d_texels));
+        r->d_texels = nullptr;
+        SRT_HIP(hipMalloc(&r->d_texels, nb));
+        r->texels_cap = nb;
+      }
+      if (!r->texel_blob.empty()) SRT_HIP(hipMemcpy(r->d_texels, r->texel_blob.data(), r->texel_blob.size(), hipMemcpyHostToDevice));
+      r->tex_dirty = false;
+    }
+  }
   r->P.nprims = (uint32_t)n;
   r->dirty = false;
   return SRT_OK;
@@ -398,16 +608,16 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (P.nprims) {
     const int bs = 256;
-    raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_bbox,
+    raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_aux, r->d_bbox,
                                                                       stats ? r->d_stats : nullptr);
   }
   raster_coarse_bin<<<dim3(P.coarse_x * P.coarse_y), dim3(256), 0, s>>>(P, r->d_bbox, r->d_lists, r->d_counts);
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
   if (stats)
-    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_rgba, so, r->d_stats);
+    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, r->d_tabs, r->d_texels, r->d_rgba, so, r->d_stats);
   else
-    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_rgba, so, nullptr);
+    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, r->d_tabs, r->d_texels, r->d_rgba, so, nullptr);
   SRT_HIP(hipGetLastError());
   r->resolved = true;
   return SRT_OK;
@@ -454,8 +664,45 @@ int srt_raster_destroy(srt_raster* r) {
   (void)hipFree(r->d_rgba);
   (void)hipFree(r->d_samples);
   (void)hipFree(r->d_stats);
+  (void)hipFree(r->d_texels);
+  (void)hipFree(r->d_aux);
+  (void)hipFree(r->d_tabs);
   (void)hipStreamDestroy(r->stream);
   delete r;
+  return SRT_OK;
+}
+
+int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widths, const uint32_t* heights,
+                           const uint8_t* const* level_texels, uint32_t* id_out) {
+  if (!r || !widths || !heights || !level_texels) return srt::fail(SRT_ERR_INVALID, "srt_raster_add_texture: NULL argument");
+  if (nlevels == 0 || nlevels > SRT_MAX_MIP_LEVELS)
+    return srt::fail(SRT_ERR_INVALID, "a texture has 1..%d mip levels (got %u)", SRT_MAX_MIP_LEVELS, nlevels);
+  srt_raster::Tex T;
+  std::memset(&T, 0, sizeof T);
+  T.nlevels = nlevels;
+  size_t total = r->texel_blob.size();
+  for (uint32_t k = 0; k < nlevels; k++) {
+    if (!widths[k] || !heights[k] || !level_texels[k]) return srt::fail(SRT_ERR_INVALID, "texture level %u is empty", k);
+    T.w[k] = widths[k]; T.h[k] = heights[k]; T.off[k] = total;
+    total += 4 * (size_t)widths[k] * heights[k];
+  }
+  if (total > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 4 GiB of texels");
+  r->texel_blob.reserve(total);
+  for (uint32_t k = 0; k < nlevels; k++)
+    r->texel_blob.insert(r->texel_blob.end(), level_texels[k], level_texels[k] + 4 * (size_t)widths[k] * heights[k]);
+  r->textures.push_back(T);
+  r->tex_dirty = true;
+  r->dirty = true;
+  if (id_out) *id_out = (uint32_t)r->textures.size() - 1;
+  return SRT_OK;
+}
+
+int srt_raster_clear_textures(srt_raster* r) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear_textures: NULL context");
+  r->textures.clear();
+  r->texel_blob.clear();
+  r->tex_dirty = true;
+  r->dirty = true;
   return SRT_OK;
 }
 
@@ -501,7 +748,7 @@ int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n) {
   if (n && !prims) return srt::fail(SRT_ERR_INVALID, "srt_raster_submit: prims is NULL");
   if (!r->have_target) return srt::fail(SRT_ERR_STATE, "srt_raster_submit before srt_raster_set_target");
   for (size_t i = 0; i < n; i++)
-    if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT)
+    if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT && prims[i].kind != SRT_PRIM_IMAGE)
       return srt::fail(SRT_ERR_INVALID, "primitive %zu has unknown kind %u", i, prims[i].kind);
   try {
     r->pending.insert(r->pending.end(), prims, prims + n);

@@ -182,3 +182,37 @@ def random_rays(seed, n):
     b[:, 0] = np.where(rng.random(n) < 0.5, 0.0, 1e-5)
     b[:, 1] = np.where(rng.random(n) < 0.3, rng.random(n) * 1.5, np.finfo(np.float32).max)
     return org, d.astype(np.float32), b
+
+
+def image_stream(seed, w, h):
+    """(prims, [level-0 textures]) with image records among translucent triangles: a big magnified image, images
+    hanging over every border (negative coordinates fold two loop values onto sample column / row 0), one minified
+    to a few samples (last mip level), one stretched, a zero-width one, non-square and odd-sized textures."""
+    rng = np.random.default_rng(seed)
+    texs = [
+        rng.integers(0, 256, (16, 16, 4), dtype=np.uint8),
+        rng.integers(0, 256, (8, 32, 4), dtype=np.uint8),     # h = 8, w = 32
+        rng.integers(0, 256, (13, 7, 4), dtype=np.uint8),     # odd sizes: levels round down
+        np.full((4, 4, 4), 255, np.uint8),
+    ]
+    texs[0][..., 3] = 255                                     # one opaque texture
+    rects = np.array([
+        [5.25, 4.5, 70.75, 60.25],        # magnified
+        [-7.5, -3.25, 20.5, 18.0],        # over the top-left corner: folds on column 0 and row 0
+        [w - 12.5, h - 9.75, w + 15.0, h + 6.0],   # over the bottom-right corner
+        [30.0, 10.0, 33.0, 12.5],         # minified: a 16x16 texture on 3x2.5 pixels
+        [10.0, 40.0, 80.0, 44.0],         # stretched
+        [50.0, 50.0, 50.0, 60.0],         # zero width: u = +inf -> clamped
+        [-0.5, 30.0, 6.5, 36.0],          # starts at -0.5
+        [40.0, 20.0, 72.0, 52.0],         # 1:1-ish for the 32-wide texture
+    ], np.float32)
+    ids = np.array([0, 1, 2, 0, 1, 3, 2, 1], np.uint32)
+    img = np.zeros(len(rects), PRIM_DTYPE)
+    img["kind"] = 3
+    img["reserved"] = ids
+    v = np.zeros((len(rects), 6), np.float32)
+    v[:, :4] = rects
+    img["v"] = v.view(np.float64).reshape(-1, 3)
+    tri = random_triangles(seed + 1, 12, w, h, 50, alpha=(0.3, 0.9))
+    prims = np.concatenate([tri[:4], img[:3], tri[4:8], img[3:6], tri[8:], img[6:]])
+    return prims, texs

@@ -23,7 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import _harness as H  # noqa: E402
-from _cases import adversarial_stream  # noqa: E402
+from _cases import adversarial_stream, image_stream  # noqa: E402
 
 SVG_DIR = os.path.join(H.REF_ROOT, "Assignments/DrawSVG/svg")
 
@@ -40,6 +40,10 @@ SVG_CASES = [
     ("degenerate1_256_ss2", "hardcore/01_degenerate_square1.svg", 256, 256, 2),
     ("lion_384_ss3", "illustration/05_lion.svg", 384, 384, 3),
     ("hexes_320x240_ss1", "illustration/02_hexes.svg", 320, 240, 1),
+    # <image> elements: rasterize_image + Sampler2DImp::sample_trilinear over the reference's own mip chains
+    ("test7_image_256_ss2", "basic/test7.svg", 256, 256, 2),
+    ("test7_image_128x160_ss3", "basic/test7.svg", 128, 160, 3),
+    ("scotty_image_300x200_ss1", "alpha/04_scotty.svg", 300, 200, 1),
 ]
 
 
@@ -56,12 +60,13 @@ def main():
         n = ref.ref_raster_svg_stream(path, w, h, sr, H.P(prims), ctypes.c_size_t(cap))
         assert 0 <= n <= cap
         prims = prims[:n].copy()
-        rgba2, ss2 = H.ref_raster_prims(prims, w, h, sr, want_samples=True)
+        tex = H.ref_svg_textures(path, w, h, sr)
+        rgba2, ss2 = H.ref_raster_prims(prims, w, h, sr, want_samples=True, textures=tex)
         assert np.array_equal(rgba, rgba2) and np.array_equal(ss.view(np.uint32), ss2.view(np.uint32)), name
         np.savez_compressed(
             os.path.join(HERE, f"raster_{name}.npz"),
             prims=prims, rgba=rgba, ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64),
-            source=np.array(svg),
+            source=np.array(svg), **(tex.to_npz() if len(tex) else {}),
         )
         print(f"{name}: {n} prims ({int((prims['kind'] == 1).sum())} triangles) rgba sha {H.sha(rgba)[:12]}")
 
@@ -75,6 +80,20 @@ def main():
             source=np.array("tests/_cases.py:adversarial_stream"),
         )
         print(f"adversarial ss{sr}: {len(prims)} prims rgba sha {H.sha(rgba)[:12]}")
+
+    # synthetic image streams: textures with the reference's mip chains, images folded over column / row 0,
+    # minified below the last level, magnified, drawn under and over translucent triangles
+    for sr in (1, 2, 4):
+        w, h = 90, 70
+        prims, level0 = image_stream(seed=77 + sr, w=w, h=h)
+        tex = H.Textures.from_level0(level0, H.ref_generate_mips)
+        rgba, ss = H.ref_raster_prims(prims, w, h, sr, want_samples=True, textures=tex)
+        np.savez_compressed(
+            os.path.join(HERE, f"raster_images_ss{sr}.npz"),
+            prims=prims, rgba=rgba, ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64),
+            source=np.array("tests/_cases.py:image_stream"), **tex.to_npz(),
+        )
+        print(f"images ss{sr}: {len(prims)} prims rgba sha {H.sha(rgba)[:12]}")
 
 
 if __name__ == "__main__":

@@ -21,10 +21,12 @@ def srt():
     return srt_amd
 
 
-def render(srt, prims, w, h, sr, samples=False):
+def render(srt, prims, w, h, sr, samples=False, textures=None):
     ren = srt.SoftwareRenderer(0)
     ren.set_render_target(None, w, h)
     ren.set_sample_rate(sr)
+    for t in range(len(textures) if textures is not None else 0):
+        assert ren.add_texture(textures.texture(t)) == t
     rgba = ren.draw_stream(prims).copy()
     ss = ren.read_samples() if samples else None
     st = ren.stats()
@@ -36,7 +38,7 @@ def render(srt, prims, w, h, sr, samples=False):
 def test_hip_matches_reference_golden(srt, path):
     g = np.load(path)
     w, h, sr = (int(x) for x in g["meta"])
-    rgba, ss, _ = render(srt, g["prims"], w, h, sr, samples=True)
+    rgba, ss, _ = render(srt, g["prims"], w, h, sr, samples=True, textures=H.Textures.from_npz(g))
     assert np.array_equal(rgba, g["rgba"]), f"{(rgba != g['rgba']).any(axis=2).sum()} pixels differ from the reference"
     assert H.sha(ss) == str(g["ss_sha256"]), "float supersample buffer differs from the reference"
 
@@ -149,3 +151,37 @@ def test_points_only_stream(srt):
         got, ss, _ = render(srt, prims, w, h, sr, samples=True)
         want, o_ss, _ = H.oracle_raster_frame(prims, w, h, sr, want_samples=True)
         assert np.array_equal(got, want) and np.array_equal(ss.view(np.uint32), o_ss.view(np.uint32))
+
+
+@pytest.mark.parametrize("sr", [1, 2, 3, 4, 8])
+def test_images_match_oracle(srt, sr):
+    """rasterize_image + Sampler2DImp::sample_trilinear on the GPU against the oracle: images over every border,
+    minified and magnified, under and over translucent triangles; textures with the oracle's own mip chains;
+    a second frame after srt_raster_clear_textures; an image record without its texture is an error."""
+    from _cases import image_stream
+
+    w, h = 75, 58
+    prims, level0 = image_stream(900 + sr, w, h)
+    tex = H.Textures.from_level0(level0, H.oracle_generate_mips)
+    rgba, ss, _ = render(srt, prims, w, h, sr, samples=True, textures=tex)
+    o_rgba, o_ss, _ = H.oracle_raster_frame(prims, w, h, sr, want_samples=True, textures=tex)
+    assert np.array_equal(rgba, o_rgba)
+    assert np.array_equal(ss.view(np.uint32), o_ss.view(np.uint32))
+
+    ren = srt.SoftwareRenderer(0)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(sr)
+    with pytest.raises(srt.SrtError):
+        ren.draw_stream(prims)                      # no textures loaded
+    for t in range(len(tex)):
+        ren.add_texture(tex.texture(t))
+    first = ren.draw_stream(prims).copy()
+    assert np.array_equal(first, o_rgba)
+    ren.clear_textures()
+    only = H.Textures.from_level0(level0[:1], H.oracle_generate_mips)
+    ren.add_texture(only.texture(0))
+    sub = prims[(prims["kind"] != 3) | (prims["reserved"] == 0)]
+    again = ren.draw_stream(sub).copy()
+    want, _, _ = H.oracle_raster_frame(sub, w, h, sr, textures=only)
+    assert np.array_equal(again, want)
+    ren.close()

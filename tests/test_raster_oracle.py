@@ -23,10 +23,23 @@ def test_goldens_present():
 def test_oracle_matches_reference_golden(path):
     g = np.load(path)
     w, h, sr = (int(x) for x in g["meta"])
-    rgba, ss, counts = H.oracle_raster_frame(g["prims"], w, h, sr, want_samples=True)
+    tex = H.Textures.from_npz(g)
+    rgba, ss, counts = H.oracle_raster_frame(g["prims"], w, h, sr, want_samples=True, textures=tex)
     assert np.array_equal(rgba, g["rgba"]), "RGBA8 differs from the reference"
     assert H.sha(ss) == str(g["ss_sha256"]), "float supersample buffer differs from the reference"
     assert counts[1] <= counts[0] and counts[2] <= counts[1]
+    # the mip chains in the fixture are the reference's (Sampler2DImp::generate_mips); the oracle's restatement
+    # must rebuild every level from level 0
+    for t in range(len(tex)):
+        chain = tex.texture(t)
+        mine = H.oracle_generate_mips(chain[0][2])
+        assert len(mine) == len(chain)
+        for k, ((w1, h1, a), (w2, h2, b)) in enumerate(zip(mine, chain)):
+            assert (w1, h1) == (w2, h2)
+            # a level built from a 1-texel-wide or 1-texel-high level reads one column / row past that level in the
+            # reference (texture.cpp:104, undefined; zeros in the oracle): only the defined levels are compared
+            if k == 0 or (chain[k - 1][0] >= 2 and chain[k - 1][1] >= 2):
+                assert np.array_equal(a, b), f"mip level {k} differs from the reference"
 
 
 def test_cfg_counts_match_survey():
