@@ -73,6 +73,15 @@ int srt_pt_add_mesh(srt_pt* pt, const float* positions, const float* normals, ui
                     int is_area_light);
 /* Object(Shape(Sphere(radius)), id, material, T). */
 int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t material);
+/* A delta light (Pathtracer::point_lights, rays/pathtracer.cpp:26-64; rays/light.{h,cpp}): radiance =
+ * Scene_Light::radiance(), trans = light.pose.transform() (column-major), angle_bounds (degrees) for spot lights
+ * only.  Shadow rays of these lights are counted as rays like every other scene.hit.  Scenes with delta lights
+ * run on the per-lane kernels. */
+#define SRT_LIGHT_DIRECTIONAL 0u
+#define SRT_LIGHT_POINT 1u
+#define SRT_LIGHT_SPOT 2u
+int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const float angle_bounds[2], const float trans[16]);
+
 /* Builds every BVH<Triangle> (leaf size 4) and the BVH<Object> (leaf size 1) exactly as the reference
  * does — or the List<> forms when use_bvh == 0 — flattens them and uploads the scene. */
 int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
@@ -145,6 +154,8 @@ long srt_pt_dump_bvh(srt_pt* pt, int which, float* boxes, uint32_t* links, size_
 int srt_pt_counters(srt_pt* pt, uint64_t out[8]);
 /* cosf/sinf of the kernel (SRT-MATH v2) for n host floats; parity tests compare them with glibc. */
 int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, float* sin_out);
+/* The kernels' atan2f (glibc 2.35's algorithm restated; Spot_Light::sample) evaluated on the device. */
+int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, float* out);
 
 int srt_pt_sync(srt_pt* pt);
 

@@ -59,6 +59,9 @@ typedef struct {
 
 typedef struct { int type; spec a, b; float ior; } material_t;
 
+/* Delta_Light (rays/light.h:57-96) */
+struct delta_light { int type, has_trans; spec radiance; float angle_bounds[2]; m4 trans, itrans; };
+
 typedef struct {
     uint64_t rays, box_tests, obj_entered, tri_tests, sphere_tests, tlas_nodes, blas_nodes, light_tri_tests;
 } counters_t;
@@ -67,6 +70,7 @@ typedef struct {
     material_t* mats; uint32_t nmats;
     object_t* objs; uint32_t nobjs;
     object_t* lights; uint32_t nlights;
+    struct delta_light* dlights; uint32_t ndlights;   /* Pathtracer::point_lights */
     int use_bvh, committed;
     bvh_t tlas;             /* BVH<Object>; tlas.prim = object order after build */
     m4 iview; float vfov, ar;
@@ -160,6 +164,68 @@ static float srt_sincosf(float y, int want_cos) {
 }
 static float srt_cosf(float x) { return srt_sincosf(x, 1); }
 static float srt_sinf(float x) { return srt_sincosf(x, 0); }
+/* SRT-MATH v2 atan2f: glibc 2.35 __ieee754_atan2f / __atanf (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c) */
+static uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static float srt_atanf(float x) {
+    static const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    static const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    static const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
+                                 9.0908870101e-02f, -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f,
+                                 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    float w, s1, s2, z;
+    int32_t hx = (int32_t)f_bits(x), ix = hx & 0x7fffffff, id;
+    if (ix >= 0x4c000000) {
+        if (ix > 0x7f800000) return x + x;
+        return (hx > 0) ? (atanhi[3] + atanlo[3]) : (-atanhi[3] - atanlo[3]);
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    z = x * x; w = z * z;
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -z : z;
+}
+static float srt_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+                pi_lo = -8.7422776573e-08f;
+    float z;
+    int32_t hx = (int32_t)f_bits(x), ix = hx & 0x7fffffff, hy = (int32_t)f_bits(y), iy = hy & 0x7fffffff, k, m;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return srt_atanf(y);
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return (m < 2) ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000)
+            return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = srt_atanf(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return bits_f(f_bits(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+static float m_atan2(const scene_t* s, float y, float x) { return s->math_mode ? srt_atan2f(y, x) : atan2f(y, x); }
+
 static float m_cos(const scene_t* s, float x) { return s->math_mode ? srt_cosf(x) : cosf(x); }
 static float m_sin(const scene_t* s, float x) { return s->math_mode ? srt_sinf(x) : sinf(x); }
 /* (float)pow(x, 2) and (float)pow(x, 5) with x promoted to double (student/bsdf.cpp:17-21,47,150) */
@@ -751,9 +817,51 @@ typedef struct { spec emissive, reflected; } pair_t;
 typedef struct { const material_t* bsdf; m4 w2o, o2w; v3 pos, out_dir, normal; uint32_t depth; } shading_t;
 static pair_t pt_trace(ctx_t* c, const ray_t* ray);
 
+/* Delta_Light::sample (rays/light.h:86-91) over Directional / Point / Spot_Light::sample (rays/light.cpp:5-31) */
+typedef struct { spec radiance; v3 direction; float distance; } light_sample_t;
+static light_sample_t delta_light_sample(const scene_t* s, const struct delta_light* l, v3 from) {
+    light_sample_t r;
+    if (l->has_trans) from = m_point(&l->itrans, from);
+    r.radiance = l->radiance;
+    if (l->type == 0) {                                              /* Directional_Light */
+        r.direction = V(0.0f, -1.0f, 0.0f);
+        r.distance = INFINITY;
+    } else {
+        r.direction = v_neg(v_unit(from));                           /* Point_Light / Spot_Light */
+        r.distance = v_norm(from);
+        if (l->type == 2) {
+            float angle = m_atan2(s, sqrtf(from.x * from.x + from.z * from.z), from.y);   /* Vec2(x, z).norm() */
+            angle = fabsf(angle * (180.0f / PI_F));                                       /* std::abs(Degrees(angle)) */
+            const float e0 = l->angle_bounds[0] / 2.0f, e1 = l->angle_bounds[1] / 2.0f;
+            const float t = min_f(max_f((angle - e0) / (e1 - e0), 0.0f), 1.0f);           /* smoothstep, lib/mathlib.h:47-50 */
+            r.radiance = s_scale(r.radiance, 1.0f - t * t * (3.0f - 2.0f * t));
+        }
+    }
+    if (l->has_trans) r.direction = m_rotate(&l->trans, r.direction);
+    return r;
+}
+
+static trace_t scene_hit(ctx_t* c, const ray_t* ray);
+/* Pathtracer::point_lighting, rays/pathtracer.cpp:327-348 */
+static spec point_lighting(ctx_t* c, const shading_t* h) {
+    const scene_t* s = c->s;
+    spec radiance = S(0, 0, 0);
+    if (mat_discrete(h->bsdf)) return radiance;
+    for (uint32_t i = 0; i < s->ndlights; i++) {
+        light_sample_t ls = delta_light_sample(s, &s->dlights[i], h->pos);
+        /* in_dir = world_to_object.rotate(sample.direction) only feeds evaluate(), which ignores it for Lambertian */
+        spec att = lambert_evaluate(s, h->bsdf, h->out_dir);
+        if (s_luma(att) == 0.0f) continue;
+        ray_t shadow = ray_make(h->pos, ls.direction, EPS_F, ls.distance - EPS_F, 0);
+        trace_t t = scene_hit(c, &shadow);
+        if (!t.hit) radiance = s_add(radiance, s_mul(att, ls.radiance));
+    }
+    return radiance;
+}
+
 static spec sample_direct(ctx_t* c, const shading_t* h) {
     const scene_t* s = c->s;
-    spec radiance = S(0, 0, 0);                 /* point_lighting: no delta lights on this path */
+    spec radiance = point_lighting(c, h);
     scatter_t in = bsdf_scatter(c, h->bsdf, h->out_dir);
     const v3 world_in = m_rotate(&h->o2w, in.direction);
     ray_t wr = ray_make(h->pos, world_in, EPS_F, FLT_MAX, 0);
@@ -911,6 +1019,22 @@ int srt_oracle_pt_add_mesh(void* h, const float* pos, const float* nrm, uint32_t
     mesh_fill(o, pos, nrm, nv, idx, ni);
     return 0;
 }
+/* Pathtracer::build_lights (rays/pathtracer.cpp:26-64): type 0 directional, 1 point, 2 spot */
+int srt_oracle_pt_add_light(void* h, uint32_t type, const float radiance[3], const float angle_bounds[2], const float T[16]) {
+    scene_t* s = (scene_t*)h;
+    if (s->committed || type > 2) return -1;
+    s->dlights = (struct delta_light*)realloc(s->dlights, (s->ndlights + 1) * sizeof(struct delta_light));
+    struct delta_light* l = &s->dlights[s->ndlights++];
+    memset(l, 0, sizeof *l);
+    l->type = (int)type;
+    l->radiance = S(radiance[0], radiance[1], radiance[2]);
+    if (angle_bounds) { l->angle_bounds[0] = angle_bounds[0]; l->angle_bounds[1] = angle_bounds[1]; }
+    l->trans = m_from(T);
+    l->itrans = m_inverse(&l->trans);
+    l->has_trans = m_ne_identity(&l->trans);
+    return 0;
+}
+
 int srt_oracle_pt_add_sphere(void* h, float radius, const float T[16], uint32_t material) {
     scene_t* s = (scene_t*)h;
     if (s->committed) return -1;
@@ -1078,6 +1202,10 @@ long srt_oracle_pt_dump_bvh(void* h, int which, float* boxes, uint32_t* links, s
 }
 
 /* cosf/sinf of SRT-MATH v2, exposed so tests can compare them with libm and with the kernel. */
+int srt_oracle_math_atan2(const float* y, const float* x, size_t n, float* out) {
+    for (size_t i = 0; i < n; i++) out[i] = srt_atan2f(y[i], x[i]);
+    return 0;
+}
 int srt_oracle_math_cos_sin(const float* x, size_t n, float* cos_out, float* sin_out) {
     for (size_t i = 0; i < n; i++) { cos_out[i] = srt_cosf(x[i]); sin_out[i] = srt_sinf(x[i]); }
     return 0;

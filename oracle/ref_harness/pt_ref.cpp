@@ -175,6 +175,19 @@ int ref_pt_add_sphere(void* h, float radius, const float T[16], uint32_t materia
   return 0;
 }
 
+// build_lights (rays/pathtracer.cpp:26-64) for one Scene_Light: type 0 directional, 1 point, 2 spot.
+int ref_pt_add_light(void* h, uint32_t type, const float radiance[3], const float angle_bounds[2], const float T[16]) {
+  RefPT* r = (RefPT*)h;
+  const Spectrum rad(radiance[0], radiance[1], radiance[2]);
+  const Scene_ID id = 1000 + (Scene_ID)r->pt->point_lights.size();
+  if (type == 0) r->pt->point_lights.push_back(PT::Delta_Light(PT::Directional_Light(rad), id, mat_from(T)));
+  else if (type == 1) r->pt->point_lights.push_back(PT::Delta_Light(PT::Point_Light(rad), id, mat_from(T)));
+  else if (type == 2)
+    r->pt->point_lights.push_back(PT::Delta_Light(PT::Spot_Light(rad, Vec2(angle_bounds[0], angle_bounds[1])), id, mat_from(T)));
+  else return -1;
+  return 0;
+}
+
 // Tail of build_scene (rays/pathtracer.cpp:165-175).
 int ref_pt_commit(void* h) {
   RefPT* r = (RefPT*)h;

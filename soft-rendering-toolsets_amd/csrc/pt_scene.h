@@ -65,6 +65,17 @@ struct Light {
   Mat4 pdfT, pdfiT;    // Object::pdf: T = I * trans, iT = itrans * I
 };
 
+// Delta_Light (rays/light.h:57-96): Directional / Point / Spot light with the object's pose.
+enum : uint32_t { DL_DIRECTIONAL = 0, DL_POINT = 1, DL_SPOT = 2 };
+struct DeltaLight {
+  uint32_t type, has_trans;
+  float radiance[3];
+  float angle_bounds[2];     // spot only (degrees, Spot_Light::angle_bounds)
+  float pad;
+  Mat4 trans, itrans;
+};
+static_assert(sizeof(DeltaLight) == 32 + 128, "delta light layout");
+
 struct Material {
   uint32_t type;
   float a[3], b[3];
@@ -98,6 +109,7 @@ struct FlatScene {
   std::vector<LightTri> light_tris;  // indexed by (global triangle index - first light triangle)
   uint32_t light_tri_first = 0;
   std::vector<Material> materials;
+  std::vector<DeltaLight> delta_lights;   // Pathtracer::point_lights, in insertion order
   uint32_t max_tlas_depth = 0, max_blas_depth = 0;  // interior-node nesting (stack frames needed)
   std::vector<WaveInterior> wave_tlas;              // empty when the root is a leaf (or in list mode)
   // Per-mesh BVH<Triangle> as interior records (both child boxes in one 64-byte fetch).  Child refs: >= 0 interior
@@ -140,6 +152,9 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
                         BuiltScene* out);
 
 Camera make_camera(const float iview[16], float vert_fov_deg, float aspect_ratio);
+
+// Delta_Light ctor: itrans = T.inverse(), has_trans = T != I.
+DeltaLight make_delta_light(uint32_t type, const float radiance[3], const float angle_bounds[2], const Mat4& trans);
 
 }  // namespace srt
 

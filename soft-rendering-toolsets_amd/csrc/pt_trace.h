@@ -24,6 +24,8 @@ struct DScene {
   const Material* materials;
   const WaveInterior* wave_tlas;   // interior nodes of the top-level tree in sweep order (pt_wave.h)
   const WaveInterior* blas_recs;   // interior records of every BVH<Triangle>
+  const DeltaLight* delta_lights;  // Pathtracer::point_lights
+  uint32_t ndelta;
   uint32_t wave_q;
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
@@ -486,6 +488,47 @@ SRT_DEV Spec emitted_along(const DScene& S, const Ray& ray, Counters& cnt) {
   return (luma(e) > 0.0f) ? e : spec(0, 0, 0);
 }
 
+// Delta_Light::sample (rays/light.h:86-91) over Directional / Point / Spot_Light::sample (rays/light.cpp:5-31).
+struct LightSample { Spec radiance; V3 direction; float distance; };
+SRT_DEV LightSample delta_light_sample(const DeltaLight& l, V3 from) {
+  if (l.has_trans) from = mat_point(l.itrans, from);
+  LightSample r;
+  r.radiance = spec(l.radiance[0], l.radiance[1], l.radiance[2]);
+  if (l.type == DL_DIRECTIONAL) {
+    r.direction = v3(0.0f, -1.0f, 0.0f);
+    r.distance = __uint_as_float(0x7f800000u);
+  } else {
+    r.direction = neg(unit(from));
+    r.distance = norm(from);
+    if (l.type == DL_SPOT) {
+      float angle = srt_atan2f(sqrtf(from.x * from.x + from.z * from.z), from.y);   // atan2(Vec2(x, z).norm(), y)
+      angle = fabsf(angle * (180.0f / kPi));                                          // std::abs(Degrees(angle))
+      const float e0 = l.angle_bounds[0] / 2.0f, e1 = l.angle_bounds[1] / 2.0f;
+      const float t = std_min(std_max((angle - e0) / (e1 - e0), 0.0f), 1.0f);         // smoothstep, lib/mathlib.h:47-50
+      const float k = 1.0f - t * t * (3.0f - 2.0f * t);
+      r.radiance = spec(k * r.radiance.r, k * r.radiance.g, k * r.radiance.b);       // float * Spectrum
+    }
+  }
+  if (l.has_trans) r.direction = mat_rotate(l.trans, r.direction);
+  return r;
+}
+
+// Pathtracer::point_lighting (rays/pathtracer.cpp:327-348) for a continuous BSDF: one shadow ray per delta light whose
+// attenuation has luma != 0; no random numbers are drawn.
+template <bool COUNT>
+SRT_DEV Spec point_lighting(const DScene& S, const Material& m, V3 position, V3 out_dir, Counters& cnt) {
+  Spec radiance = spec(0, 0, 0);
+  for (uint32_t i = 0; i < S.ndelta; i++) {
+    const LightSample ls = delta_light_sample(S.delta_lights[i], position);
+    const Spec att = lambert_evaluate(m, out_dir);    // bsdf.evaluate(out_dir, in_dir): the Lambertian ignores in_dir
+    if (luma(att) == 0.0f) continue;
+    const Ray shadow = make_ray(position, ls.direction, kEps, ls.distance - kEps);
+    const Hit h = scene_hit<COUNT>(S, shadow, cnt);
+    if (!h.hit) radiance = radiance + att * ls.radiance;
+  }
+  return radiance;
+}
+
 struct Bounce { Spec direct, atten; float inv_pdf; uint32_t discrete; };
 
 // Pathtracer::trace_pixel for pixel (x, y); the RNG must already be keyed.
@@ -512,7 +555,8 @@ SRT_DEV Spec path_sample(const DScene& S, uint32_t x, uint32_t y, Rng& rng, Coun
     const bool discrete = is_discrete(m.type);
 
     // ---- sample_direct_lighting ----
-    Spec radiance = spec(0, 0, 0);  // point_lighting(): no delta lights on this path
+    Spec radiance = spec(0, 0, 0);  // point_lighting() returns {} for a discrete BSDF
+    if (!discrete && S.ndelta) radiance = point_lighting<COUNT>(S, m, sf.position, out_dir, cnt);
     const Scatter s1 = scatter(m, out_dir, rng);
     const V3 world_in = frame_to_world(fr, s1.dir);
     const Ray r1 = make_ray(sf.position, world_in, kEps, FLT_MAX);

@@ -104,8 +104,29 @@ void Pathtracer::build_scene(Scene& layout_scene) {
             } else {
                 add_mesh(obj.posed_mesh(), is_light);
             }
-        } else if(item.is<Scene_Light>() || item.is<Scene_Particles>()) {
-            if(!warned) warn("HIP path tracer: delta/environment lights and particles are not on this path yet; ignored");
+        } else if(item.is<Scene_Light>()) {
+            // build_lights (rays/pathtracer.cpp:26-64): directional / point / spot lights become delta lights
+            const Scene_Light& light = item.get<Scene_Light>();
+            const Spectrum r = light.radiance();
+            const float rad[3] = {r.r, r.g, r.b};
+            const float ab[2] = {light.opt.angle_bounds.x, light.opt.angle_bounds.y};
+            const Mat4 pose = light.pose.transform();
+            switch(light.opt.type) {
+            case Light_Type::directional:
+                check(srt_pt_add_light(ctx, SRT_LIGHT_DIRECTIONAL, rad, ab, pose.data), "srt_pt_add_light");
+                break;
+            case Light_Type::point:
+                check(srt_pt_add_light(ctx, SRT_LIGHT_POINT, rad, ab, pose.data), "srt_pt_add_light");
+                break;
+            case Light_Type::spot:
+                check(srt_pt_add_light(ctx, SRT_LIGHT_SPOT, rad, ab, pose.data), "srt_pt_add_light");
+                break;
+            default:   // sphere / hemisphere / rectangle: environment lights (Env_Light) are not on this path yet
+                if(!warned) warn("HIP path tracer: environment lights are not on this path yet; ignored");
+                warned = true;
+            }
+        } else if(item.is<Scene_Particles>()) {
+            if(!warned) warn("HIP path tracer: particles are not on this path yet; ignored");
             warned = true;
         }
     });

@@ -136,6 +136,27 @@ def pt_scene(name):
         s = scenes.cornell_box("cbox")
         s["materials"][6] = {"type": scenes.REFRACT, "a": np.ones(3, np.float32), "b": np.zeros(3, np.float32), "ior": 1.5}
         return s
+    if name == "cbox_deltalights":
+        # the Cornell box (area light kept) plus one light of each Delta_Light kind: a posed point light, a spot light
+        # looking down with a smoothstep cone, a tilted directional light; the discrete BSDFs skip point_lighting
+        s = scenes.cornell_box("cbox")
+
+        def pose(t, rx=0.0, rz=0.0):
+            cx, sx, cz, sz = np.cos(rx), np.sin(rx), np.cos(rz), np.sin(rz)
+            Rx = np.array([[1, 0, 0, 0], [0, cx, -sx, 0], [0, sx, cx, 0], [0, 0, 0, 1]], np.float32)
+            Rz = np.array([[cz, -sz, 0, 0], [sz, cz, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+            Tm = np.eye(4, dtype=np.float32)
+            Tm[:3, 3] = t
+            return np.ascontiguousarray((Tm @ Rz @ Rx).T.astype(np.float32).reshape(16))   # column-major
+
+        s["lights"] = [
+            {"type": 1, "radiance": np.array([0.6, 0.5, 0.4], np.float32), "T": pose((0.3, 0.55, 0.2))},
+            {"type": 2, "radiance": np.array([2.0, 2.0, 2.5], np.float32), "angle_bounds": np.array([35.0, 70.0], np.float32),
+             "T": pose((-0.25, 0.9, -0.1), rx=0.35, rz=-0.2)},
+            {"type": 0, "radiance": np.array([0.15, 0.2, 0.15], np.float32), "T": pose((0.0, 0.0, 0.0), rx=0.5, rz=0.3)},
+            {"type": 1, "radiance": np.array([0.2, 0.2, 0.2], np.float32), "T": np.eye(4, dtype=np.float32).reshape(16)},   # at the origin, no transform
+        ]
+        return s
     if name == "cbox_nolight":
         s = scenes.cornell_box("cbox_lambertian")
         s["objects"] = s["objects"][:-1]   # no area light: sample_area_lights returns the zero vector -> NaN rays
@@ -157,6 +178,9 @@ def scene_digest(scene):
                      + np.asarray(o["idx"], np.uint32).tobytes() + bytes([int(o["is_light"])]))
         else:
             h.update(np.asarray([o["radius"]], np.float32).tobytes())
+    for l in scene.get("lights", []):
+        h.update(np.asarray([l["type"]], np.int32).tobytes() + np.asarray(l["radiance"], np.float32).tobytes()
+                 + np.asarray(l.get("angle_bounds", (0.0, 0.0)), np.float32).tobytes() + np.asarray(l["T"], np.float32).tobytes())
     c = scene["camera"]
     h.update(np.asarray(c["iview"], np.float32).tobytes() + np.asarray([c["vfov"], c["ar"]], np.float32).tobytes())
     return h.hexdigest()

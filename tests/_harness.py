@@ -224,6 +224,8 @@ class _SceneFeeder:
                                int(o["material"]), bool(o["is_light"]))
             else:
                 self._add_sphere(float(o["radius"]), _f32(o["T"]), int(o["material"]))
+        for l in scene.get("lights", []):   # delta lights: {"type": 0 directional | 1 point | 2 spot, "radiance", "angle_bounds", "T"}
+            self._add_light(int(l["type"]), _f32(l["radiance"]), _f32(l.get("angle_bounds", (0.0, 0.0))), _f32(l["T"]))
         self._commit()
         c = scene["camera"]
         self._set_camera(_f32(c["iview"]), float(c["vfov"]), float(c["ar"]))
@@ -247,6 +249,9 @@ class RefPT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.ref_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_light(self, type_, radiance, angle_bounds, T):
+        assert self.lib.ref_pt_add_light(self.h_, type_, P(radiance), P(angle_bounds), P(T)) == 0
 
     def _commit(self):
         assert self.lib.ref_pt_commit(self.h_) == 0
@@ -309,6 +314,9 @@ class OraclePT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.srt_oracle_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_light(self, type_, radiance, angle_bounds, T):
+        assert self.lib.srt_oracle_pt_add_light(self.h_, type_, P(radiance), P(angle_bounds), P(T)) == 0
 
     def _commit(self):
         rc = self.lib.srt_oracle_pt_commit(self.h_, int(self._use_bvh))
@@ -405,6 +413,9 @@ class EmuPT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.emu_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_light(self, type_, radiance, angle_bounds, T):
+        pass   # scene.hit only
 
     def _commit(self):
         assert self.lib.emu_commit(self.h_, int(self.use_bvh)) == 0

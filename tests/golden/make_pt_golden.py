@@ -35,6 +35,8 @@ CASES = [
     ("cbox_blob2048_mirror", 40, 40, 5, True, 2048, None),
     ("cbox_refract", 32, 32, 8, True, 1024, None),              # BSDF_Refract stub: zero direction -> NaN rays
     ("cbox_nolight", 32, 32, 4, True, 1024, (16, 16, 4)),       # empty area-light list -> every sample invalid
+    ("cbox_deltalights", 48, 40, 8, True, 3072, (24, 20, 8)),   # point + spot + directional lights: point_lighting's shadow rays
+    ("cbox_deltalights", 32, 24, 4, False, 1024, None),
 ]
 SEED = 20260331
 

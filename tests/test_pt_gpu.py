@@ -105,6 +105,43 @@ def test_kernel_math_is_glibc_sincosf(srt):
     pt.close()
 
 
+def test_kernel_math_is_glibc_atan2f(srt):
+    from test_pt_oracle import _atan2_args
+    import ctypes
+
+    pt = srt.Pathtracer(0)
+    y, x = _atan2_args(6, 300_000)
+    got = pt.math_atan2(y, x)
+    want = np.zeros_like(y)
+    H.oracle().srt_oracle_math_atan2(H.P(y), H.P(x), ctypes.c_size_t(len(y)), H.P(want))
+    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all()
+    pt.close()
+
+
+def test_delta_lights(srt):
+    """Point, spot and directional lights (Pathtracer::point_lighting): per-lane kernels against the oracle, the
+    shadow rays counted; the wave kernel refuses such scenes instead of ignoring the lights."""
+    scene = pt_scene("cbox_deltalights")
+    w, h, spp = 40, 32, 5
+    want = H.OraclePT(scene, w, h, 8, True).epoch(3, 2, spp)
+    plain = H.OraclePT(pt_scene("cbox"), w, h, 8, True).epoch(3, 2, spp)
+    assert not bits_equal(want, plain)
+    pt = make_pt(srt, scene, w, h, 8, True)
+    rays = []
+    for mode in (0, 1, 4):
+        pt.set_kernel(mode)
+        pt.ray_count(reset=True)
+        assert bits_equal(pt.render_epoch(3, 2, spp), want), f"kernel mode {mode}"
+        rays.append(pt.ray_count()[0])
+    assert rays[0] == rays[1] == rays[2]
+    for mode in (2, 5):
+        pt.set_kernel(mode)
+        with pytest.raises(srt.SrtError):
+            pt.render_epoch(3, 2, spp)
+    pt.close()
+
+
 def test_epoch_image_and_tiling(srt):
     """cfg3-shaped run at reduced size: epoch images equal the oracle's; sharding the image over 1, 2 and 3
     ranks (tile round-robin) produces the same pixels; the device untile + accumulate path equals the host one."""

@@ -90,6 +90,31 @@ def test_srtmath_matches_libm():
         assert c[i] == np.float32(libm.cosf(float(x[i]))) and s[i] == np.float32(libm.sinf(float(x[i]))), float(x[i])
 
 
+def _atan2_args(seed, n):
+    rng = np.random.default_rng(seed)
+    y = np.concatenate([rng.random(n, dtype=np.float32) * 10, rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                        np.array([0.0, -0.0, 1.0, 0.0, 5.0, np.inf, np.inf, 1e-30, 3.0, 2.0 ** 70], np.float32)])
+    x = np.concatenate([(rng.random(n, dtype=np.float32) - 0.5) * 20, rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                        np.array([1.0, -1.0, 1.0, 0.0, -0.0, np.inf, -np.inf, -1e30, 0.0, 1.0], np.float32)])
+    return np.ascontiguousarray(y), np.ascontiguousarray(x)
+
+
+def test_srt_math_atan2_is_glibc():
+    """SRT-MATH v2's atan2f restates glibc 2.35's __ieee754_atan2f / __atanf (Spot_Light::sample): bit-identical to
+    the host libm on the renderer's range, random bit patterns and the special cases."""
+    y, x = _atan2_args(2, 400_000)
+    out = np.zeros_like(y)
+    H.oracle().srt_oracle_math_atan2(H.P(y), H.P(x), ctypes.c_size_t(len(y)), H.P(out))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atan2f.restype = ctypes.c_float
+    libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    idx = np.random.default_rng(1).integers(0, len(y), 40000)
+    idx[:10] = np.arange(len(y) - 10, len(y))
+    for i in idx:
+        want = np.float32(libm.atan2f(float(y[i]), float(x[i])))
+        assert out[i].view(np.uint32) == want.view(np.uint32) or (np.isnan(out[i]) and np.isnan(want)), (float(y[i]), float(x[i]))
+
+
 def test_accumulate_running_mean():
     rng = np.random.default_rng(3)
     acc = np.zeros(300, np.float32)
