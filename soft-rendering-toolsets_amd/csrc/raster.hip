@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -39,8 +40,10 @@ constexpr int WAVE = 64;
 struct RasterParams {
   uint32_t w, h, sr;
   uint32_t ssw, ssh;
-  uint32_t tile_px;  // pixels per tile side
-  uint32_t tile_s;   // samples per tile side
+  uint32_t tile_px;  // pixels per tile, x
+  uint32_t tile_s;   // samples per tile, x (<= TS)
+  uint32_t tile_py;  // pixels per tile, y
+  uint32_t tile_sy;  // samples per tile, y (<= 16 for sample rates up to 16, else <= 32)
   uint32_t tiles_x, tiles_y;
   uint32_t nprims;
   uint32_t coarse_tiles;         // a coarse bin is coarse_tiles x coarse_tiles tiles
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(256) void raster_coarse_bin(RasterParams P, const i
   __shared__ uint32_t wave_cnt[4];
   const uint32_t bin = blockIdx.x;
   const int cx = (int)(bin % P.coarse_x), cy = (int)(bin / P.coarse_x);
-  const int span = (int)(P.coarse_tiles * P.tile_s);
-  const int x0 = cx * span, y0 = cy * span, x1 = x0 + span - 1, y1 = y0 + span - 1;
+  const int span = (int)(P.coarse_tiles * P.tile_s), span_y = (int)(P.coarse_tiles * P.tile_sy);
+  const int x0 = cx * span, y0 = cy * span_y, x1 = x0 + span - 1, y1 = y0 + span_y - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* out = lists + (size_t)bin * P.list_stride;
   uint32_t total = 0;
@@ -220,7 +223,9 @@ __device__ __forceinline__ float4 sample_image(const ImageAux& A, const uint8_t*
 // ---------------------------------------------------------------------------------------------
 // Pass 2: one wave per tile.
 // ---------------------------------------------------------------------------------------------
-template <bool STATS>
+// TSY: tile height in samples (16: 8 KiB of LDS per tile and twice the waves per CU - the kernel is bound by the
+// latency of a wave's own instruction stream, not by throughput - and tighter culling; 32 for sample rates > 16).
+template <bool STATS, int TSY>
 __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
@@ -230,21 +235,21 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
                                                      uint32_t* __restrict__ rgba_out,
                                                      float4* __restrict__ samples_out,
                                                      unsigned long long* __restrict__ stats) {
-  __shared__ float4 tile[TS * TS];  // 16 KiB: the tile's slice of super_sample_buffer
-  __shared__ double rowy[TS];       // y / sample_rate for each tile row (fp64 division done once)
+  __shared__ float4 tile[TS * TSY];  // 8 / 16 KiB: the tile's slice of super_sample_buffer
+  __shared__ double rowy[TSY];       // y / sample_rate for each tile row (fp64 division done once)
 
   const int lane = threadIdx.x;
   const int tx = blockIdx.x % P.tiles_x;
   const int ty = blockIdx.x / P.tiles_x;
-  const int sx0 = tx * (int)P.tile_s, sy0 = ty * (int)P.tile_s;  // tile origin (samples)
-  const int tsw = min((int)P.tile_s, (int)P.ssw - sx0);          // valid extent inside the target
-  const int tsh = min((int)P.tile_s, (int)P.ssh - sy0);
+  const int sx0 = tx * (int)P.tile_s, sy0 = ty * (int)P.tile_sy;  // tile origin (samples)
+  const int tsw = min((int)P.tile_s, (int)P.ssw - sx0);           // valid extent inside the target
+  const int tsh = min((int)P.tile_sy, (int)P.ssh - sy0);
   const int sx1 = sx0 + tsw - 1, sy1 = sy0 + tsh - 1;
 
   // clear_target: every sample starts at 255.0f (software_renderer.h:93-98)
   const float4 white = make_float4(255.0f, 255.0f, 255.0f, 255.0f);
-  for (int i = lane; i < TS * TS; i += WAVE) tile[i] = white;
-  if (lane < TS) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
+  for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
+  if (lane < TSY) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
 
   const int lx = lane & (TS - 1);
   const int lrow = lane >> 5;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
   // resolve (cpp:586-619): box sum with x-offset outer / y-offset inner, true division, truncation
   const int sr = (int)P.sr;
   const int pw = tsw / sr, ph = tsh / sr;
-  const int px0 = tx * (int)P.tile_px, py0 = ty * (int)P.tile_px;
+  const int px0 = tx * (int)P.tile_px, py0 = ty * (int)P.tile_py;
   const float denom = (float)((size_t)P.sr * (size_t)P.sr);
   for (int k = lane; k < pw * ph; k += WAVE) {
     const int pxl = k % pw, pyl = k / pw;
@@ -614,10 +619,13 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   raster_coarse_bin<<<dim3(P.coarse_x * P.coarse_y), dim3(256), 0, s>>>(P, r->d_bbox, r->d_lists, r->d_counts);
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
-  if (stats)
-    raster_tiles<true><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, r->d_tabs, r->d_texels, r->d_rgba, so, r->d_stats);
-  else
-    raster_tiles<false><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, r->d_tabs, r->d_texels, r->d_rgba, so, nullptr);
+#define SRT_TILES(STATS_, TSY_, ST_)                                                                                       \
+  raster_tiles<STATS_, TSY_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, \
+                                                                 r->d_tabs, r->d_texels, r->d_rgba, so, ST_)
+  const int tsy = P.tile_sy > 16 ? 32 : (P.tile_sy > 8 ? 16 : 8);
+  if (stats) { if (tsy == 32) SRT_TILES(true, 32, r->d_stats); else if (tsy == 16) SRT_TILES(true, 16, r->d_stats); else SRT_TILES(true, 8, r->d_stats); }
+  else { if (tsy == 32) SRT_TILES(false, 32, nullptr); else if (tsy == 16) SRT_TILES(false, 16, nullptr); else SRT_TILES(false, 8, nullptr); }
+#undef SRT_TILES
   SRT_HIP(hipGetLastError());
   r->resolved = true;
   return SRT_OK;
@@ -722,8 +730,12 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   P.ssw = width * sample_rate; P.ssh = height * sample_rate;
   P.tile_px = TS / sample_rate;
   P.tile_s = P.tile_px * sample_rate;
+  uint32_t tsy = sample_rate <= 16 ? 16 : TS;
+  if (getenv("SRT_RASTER_TSY")) { const uint32_t e = (uint32_t)atoi(getenv("SRT_RASTER_TSY")); if ((e == 8 || e == 16 || e == 32) && sample_rate <= e) tsy = e; }   // experiments
+  P.tile_py = tsy / sample_rate;
+  P.tile_sy = P.tile_py * sample_rate;
   P.tiles_x = (width + P.tile_px - 1) / P.tile_px;
-  P.tiles_y = (height + P.tile_px - 1) / P.tile_px;
+  P.tiles_y = (height + P.tile_py - 1) / P.tile_py;
   if (realloc_px) {
     if (r->d_rgba) SRT_HIP(hipFree(r->d_rgba));
     r->d_rgba = nullptr;

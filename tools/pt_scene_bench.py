@@ -11,8 +11,13 @@ size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 if name.startswith("blob"):
     scene = scenes.cornell_with_mesh(int(name[4:]), "glass")
-else:
+elif name in ("cbox", "cbox_lambertian"):
     scene = scenes.cornell_box(name)
+else:   # any named test scene (tests/_cases.py)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from _cases import pt_scene
+    scene = pt_scene(name)
+    scene.setdefault("name", name)
 pt = srt_amd.Pathtracer(0)
 pt.set_params(size, size, spp, 8, True)
 t = time.perf_counter(); pt.build_scene(scene); print(f"build_scene {time.perf_counter()-t:.2f} s ({scene['name']})")
