@@ -75,8 +75,7 @@ int srt_pt_add_mesh(srt_pt* pt, const float* positions, const float* normals, ui
 int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t material);
 /* A delta light (Pathtracer::point_lights, rays/pathtracer.cpp:26-64; rays/light.{h,cpp}): radiance =
  * Scene_Light::radiance(), trans = light.pose.transform() (column-major), angle_bounds (degrees) for spot lights
- * only.  Shadow rays of these lights are counted as rays like every other scene.hit.  Scenes with delta lights
- * run on the per-lane kernels. */
+ * only.  Shadow rays of these lights are counted as rays like every other scene.hit. */
 #define SRT_LIGHT_DIRECTIONAL 0u
 #define SRT_LIGHT_POINT 1u
 #define SRT_LIGHT_SPOT 2u

@@ -302,12 +302,13 @@ int wave_trav(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   const int m = pt->kernel_mode;
   if (m == 1 || m == 4) return -1;
-  if (!F.delta_lights.empty()) return -1;   // point_lighting's shadow rays are only in the per-lane kernels so far
+  const bool lights = !F.delta_lights.empty();   // point_lighting's shadow batches: sweeps only, not the stamped build
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
   const bool flat_fits = flat_walk_fits(F);
-  if (m == 2 || m == 3) return sweeps_fit ? (blas ? 1 : 0) : -1;
-  if (m == 5) return flat_fits ? 2 : -1;
+  if (m == 2) return sweeps_fit ? (blas ? 1 : 0) : -1;
+  if (m == 3) return (sweeps_fit && !lights) ? (blas ? 1 : 0) : -1;
+  if (m == 5) return (flat_fits && !lights) ? 2 : -1;
   // auto: sweeps for small scenes of single-leaf meshes.  Scenes with a real BVH<Triangle> are bound by the vector
   // memory path (64 lanes fetching 64-byte records from 64 different cache lines), where the lane-per-sample
   // kernel is still ahead of the flattened walk on MI355X (325 vs 270 Mrays/s on the 131 k-triangle test scene)
@@ -342,8 +343,10 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const bool stamp = pt->kernel_mode == 3;
   const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
   const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * 6 * 64 * sizeof(float);  // 4 waves x (Q - 1) x 3 rays x 2 fields
-  const void* kern = stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0> : trav == 1 ? (const void*)pt_wave_kernel<true, 1> : (const void*)pt_wave_kernel<true, 2>)
-                           : (trav == 0 ? (const void*)pt_wave_kernel<false, 0> : trav == 1 ? (const void*)pt_wave_kernel<false, 1> : (const void*)pt_wave_kernel<false, 2>);
+  const bool dl = !F.delta_lights.empty();
+  const void* kern = stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false> : (const void*)pt_wave_kernel<true, 2, false>)
+                     : dl  ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, true> : (const void*)pt_wave_kernel<false, 1, true>)
+                           : (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<false, 1, false> : (const void*)pt_wave_kernel<false, 2, false>);
   if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode || pt->wave_kern != kern) {
     pt->wave_mode = pt->kernel_mode;
     pt->wave_kern = kern;
@@ -384,13 +387,15 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     if (n) {
       SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
-#define SRT_LAUNCH_WAVE(STAMP_, TRAV_)                                                                                        \
-  pt_wave_kernel<STAMP_, TRAV_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, \
-                                                                              DS.lights, DS.light_tris, DS.materials,           \
-                                                                              DS.wave_tlas, DS.blas_recs, P.records, P.sample_out)
+#define SRT_LAUNCH_WAVE(STAMP_, TRAV_, DL_)                                                                                   \
+  pt_wave_kernel<STAMP_, TRAV_, DL_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm,       \
+                                                                                   DS.nodes, DS.lights, DS.light_tris,          \
+                                                                                   DS.materials, DS.wave_tlas, DS.blas_recs,    \
+                                                                                   P.records, P.sample_out)
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
-      if (stamp) { if (trav == 0) SRT_LAUNCH_WAVE(true, 0); else if (trav == 1) SRT_LAUNCH_WAVE(true, 1); else SRT_LAUNCH_WAVE(true, 2); }
-      else { if (trav == 0) SRT_LAUNCH_WAVE(false, 0); else if (trav == 1) SRT_LAUNCH_WAVE(false, 1); else SRT_LAUNCH_WAVE(false, 2); }
+      if (stamp) { if (trav == 0) SRT_LAUNCH_WAVE(true, 0, false); else if (trav == 1) SRT_LAUNCH_WAVE(true, 1, false); else SRT_LAUNCH_WAVE(true, 2, false); }
+      else if (dl) { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, true); else SRT_LAUNCH_WAVE(false, 1, true); }
+      else { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, false); else if (trav == 1) SRT_LAUNCH_WAVE(false, 1, false); else SRT_LAUNCH_WAVE(false, 2, false); }
 #undef SRT_LAUNCH_WAVE
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;

@@ -223,7 +223,7 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // STAMP = true is a diagnostic build: s_memtime deltas of the loop's sections are summed per wave and added to
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
-template <bool STAMP, int TRAV>
+template <bool STAMP, int TRAV, bool DL>
 __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
@@ -277,6 +277,15 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
   Spec att = spec(0, 0, 0);                              // s1.attenuation (== evaluate(out) for Lambertian)
   float pdf4 = 1.0f, pdf_area = 0.0f;
   bool discrete = false;
+
+  // DL (scenes with delta lights, Pathtracer::point_lighting): after a continuous-BSDF bounce's A/B/C batch the lane
+  // traces the shadow rays of the lights, three per batch, from the same origin; the bounce's direct term is
+  // completed when the last shadow batch returns, then the held C hit decides how the path goes on
+  bool sh_phase = false, sa1 = false, sa2 = false;       // a shadow batch is in flight; its slots 1, 2 carry a ray
+  uint32_t light_i = 0, held_chit = kRetMiss;
+  Spec pl = spec(0, 0, 0), dA_keep = spec(0, 0, 0), d6_keep = spec(0, 0, 0);
+  V3 dC_keep = v3(0, 0, 1);                              // direction of the C ray (the next shade needs it)
+  float sb1[3] = {0.0f, 0.0f, 0.0f};                     // dist_bounds.y of the shadow rays: distance - EPS_F
 
   // TRAV == 2: the flattened walk's per-lane state and stack persist across iterations of the loop below, so the
   // wave can stop walking once kFlatReady lanes have a finished batch, shade / refill those, and resume the rest
@@ -357,9 +366,13 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
     SECTION_END(ST_REFILL)
 
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
-    if (TRAV != 2) cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
+    if (TRAV != 2) {
+      if (DL && sh_phase) cnt.v[C_RAYS] += alive ? (1u + (sa1 ? 1u : 0u) + (sa2 ? 1u : 0u)) : 0u;
+      else cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
+    }
+    const bool shb = DL && sh_phase;
     const float rb0[3] = {cb0, cb0, cb0};
-    const float rb1[3] = {cb1, cb1, cb1};
+    const float rb1[3] = {shb ? sb1[0] : cb1, shb ? sb1[1] : cb1, shb ? sb1[2] : cb1};
     Hit res[3];
     bool batch_ready = alive;                            // the lane's batch has been traced completely
     if (TRAV == 2) {
@@ -474,8 +487,31 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
 
     // ---------------- 3. finish the previous bounce / unpack the burst, then terminate or shade ----------------
     if (batch_ready) {
-      uint32_t chit;                                    // packed closest hit that decides how the current path goes on
-      if (burst) {
+      uint32_t chit = kRetMiss;                         // packed closest hit that decides how the current path goes on
+      bool more_shadow = false;                         // another batch goes out before the path is resolved
+      if (DL && sh_phase) {
+        // a shadow batch returned: radiance += attenuation * sample.radiance for the unoccluded lights, in light order
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          if (light_i + (uint32_t)j < S.ndelta) {
+            const LightSample ls = delta_light_sample(S.delta_lights[light_i + (uint32_t)j], org);
+            if (!res[j].hit) pl = pl + att * ls.radiance;
+          }
+        }
+        light_i += 3u;
+        if (light_i < S.ndelta) more_shadow = true;
+        else {
+          Spec radiance = pl;                           // sample_direct_lighting, student/pathtracer.cpp:78-172
+          radiance = radiance + dA_keep;
+          radiance = radiance - dA_keep;
+          radiance = radiance + d6_keep;
+          float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
+          rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+          sh_phase = false;
+          chit = held_chit;
+          d[2] = dC_keep;
+        }
+      } else if (burst) {
         // burst order: slot 0 = sample s_first (continues now), slots 1, 2 = the next samples (parked)
         chit = pack_ret(res[0]);
         pend[0] = pack_ret(res[1]);
@@ -491,23 +527,44 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
             radiance = radiance + direct;
           } else {
             const Spec direct = (eA * att) * (1.0f / pdf4);
-            radiance = radiance + direct;
-            radiance = radiance - direct;
             const float pdf = (pdf4 + pdf_area) / 2.0f;
             const Spec d6 = (eB * att) * (1.0f / pdf);
-            radiance = radiance + d6;
+            if (DL && S.ndelta != 0u && luma(att) != 0.0f) {
+              // point_lighting comes first in the sum: hold the two terms until the shadow rays are back
+              dA_keep = direct; d6_keep = d6; pl = spec(0, 0, 0);
+              light_i = 0; held_chit = pack_ret(res[2]); dC_keep = d[2];
+              sh_phase = true; more_shadow = true;
+            } else {
+              radiance = radiance + direct;
+              radiance = radiance - direct;
+              radiance = radiance + d6;
+            }
           }
-          float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-          rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+          if (!(DL && sh_phase)) {
+            float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
+            rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+          }
         }
         chit = pack_ret(res[2]);
+      }
+      if (DL && more_shadow) {
+        // next shadow batch: lights light_i .. light_i + 2 (Ray(hit.pos, sample.direction, {EPS_F, distance - EPS_F}))
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const uint32_t li = light_i + (uint32_t)j < S.ndelta ? light_i + (uint32_t)j : light_i;
+          const LightSample ls = delta_light_sample(S.delta_lights[li], org);
+          d[j] = unit(ls.direction);
+          sb1[j] = ls.distance - kEps;
+        }
+        sa1 = light_i + 1u < S.ndelta; sa2 = light_i + 2u < S.ndelta;
+        if (TRAV == 2) need_begin = true;
       }
       SECTION_END(ST_POST)
       // Resolve the current path; when it ends, the next parked camera hit (if any) takes over in the same cycle.
       bool need_shade = false;
       Spec e = spec(0, 0, 0);
       uint32_t mi = 0;
-      for (int guard = 0; guard < 3 && !need_shade && alive; guard++) {
+      for (int guard = 0; guard < 3 && !need_shade && alive && !(DL && more_shadow); guard++) {
         const Hit ch = unpack_ret(0.0f, chit);
         bool terminal = !ch.hit;                         // student/pathtracer.cpp:174-218
         e = spec(0, 0, 0);

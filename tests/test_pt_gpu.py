@@ -120,8 +120,9 @@ def test_kernel_math_is_glibc_atan2f(srt):
 
 
 def test_delta_lights(srt):
-    """Point, spot and directional lights (Pathtracer::point_lighting): per-lane kernels against the oracle, the
-    shadow rays counted; the wave kernel refuses such scenes instead of ignoring the lights."""
+    """Point, spot and directional lights (Pathtracer::point_lighting): the per-lane kernels and the wave kernel's
+    shadow batches against the oracle, the shadow rays counted; the builds without point_lighting (flattened walk,
+    stamped) refuse such scenes instead of ignoring the lights."""
     scene = pt_scene("cbox_deltalights")
     w, h, spp = 40, 32, 5
     want = H.OraclePT(scene, w, h, 8, True).epoch(3, 2, spp)
@@ -129,13 +130,13 @@ def test_delta_lights(srt):
     assert not bits_equal(want, plain)
     pt = make_pt(srt, scene, w, h, 8, True)
     rays = []
-    for mode in (0, 1, 4):
+    for mode in (0, 1, 2, 4):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         assert bits_equal(pt.render_epoch(3, 2, spp), want), f"kernel mode {mode}"
         rays.append(pt.ray_count()[0])
-    assert rays[0] == rays[1] == rays[2]
-    for mode in (2, 5):
+    assert rays[0] == rays[1] == rays[2] == rays[3]
+    for mode in (3, 5):
         pt.set_kernel(mode)
         with pytest.raises(srt.SrtError):
             pt.render_epoch(3, 2, spp)
