@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void pt_unit_kernel(DScene S, TileMap T, uint64
       Rng rng;
       rng.key(seed, y * S.w + x, sample_base + u % samples);
       const Spec p = path_sample<false>(S, x, y, rng, cnt);
-      reinterpret_cast<float4*>(sample_out)[u] = make_float4(p.r, p.g, p.b, 0.0f);
+      reinterpret_cast<float4*>(sample_out)[(size_t)(u % samples) * (total_units / samples) + u / samples] = make_float4(p.r, p.g, p.b, 0.0f);
     }
   }
   unsigned long long r = cnt.v[C_RAYS];
@@ -380,6 +380,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.sample_out = pt->d_samples; P.records = pt->d_records;
     // one unit per lane per queue atomic: with the 512-unit grabs of the first version the last grabs decided the
     // launch time (a 1/8 image shard ran at 56 % of the full-image rate; 83 % with 64, and the full image gained 6 %)
+    P.npix = px;
     P.chunk = getenv("SRT_WAVE_CHUNK") ? (uint32_t)atoi(getenv("SRT_WAVE_CHUNK")) : kChunk;
     P.flat_ready = getenv("SRT_FLAT_READY") ? (uint32_t)atoi(getenv("SRT_FLAT_READY")) : kFlatReady;
     P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;

@@ -64,6 +64,7 @@ struct WaveParams {
   unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
   unsigned long long* stamps;
   uint32_t chunk;            // units a wave reserves per queue atomic
+  uint32_t npix;             // pixel slots of the launch; sample_out is [sample][pixel slot] so that the reduction reads coalesced
   uint32_t flat_ready;       // TRAV 2: lanes with a finished batch that make the wave leave the walk
   uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
 };
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
           L = dk + ind;
         }
         const Spec out = ((level == 0) ? e : spec(0, 0, 0)) + L;
-        reinterpret_cast<float4*>(P.sample_out)[(size_t)pixel_slot * P.samples + s_cur] = make_float4(out.r, out.g, out.b, 0.0f);
+        reinterpret_cast<float4*>(P.sample_out)[(size_t)s_cur * P.npix + pixel_slot] = make_float4(out.r, out.g, out.b, 0.0f);
         // next sample of the unit: its camera hit is already known
         s_cur++;
         if (s_cur < s_first + s_count) {
@@ -684,9 +685,10 @@ __global__ void pt_reduce_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t sam
   Spec acc = spec(0, 0, 0);
   uint32_t sampled = 0;
   if (!first) { acc = spec(running[4 * (size_t)p], running[4 * (size_t)p + 1], running[4 * (size_t)p + 2]); sampled = __float_as_uint(running[4 * (size_t)p + 3]); }
-  const float4* src = reinterpret_cast<const float4*>(sample_out) + (size_t)p * samples;
+  const uint32_t npix = T.local_tiles * T.tile_w * T.tile_h;
+  const float4* src = reinterpret_cast<const float4*>(sample_out) + p;   // [sample][pixel slot]: consecutive lanes, consecutive float4
   for (uint32_t s = 0; s < samples; s++) {
-    const float4 q = src[s];
+    const float4 q = src[(size_t)s * npix];
     const Spec v = spec(q.x, q.y, q.z);
     if (valid(v)) { acc = acc + v; sampled++; }
   }
