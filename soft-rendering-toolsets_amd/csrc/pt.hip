@@ -317,6 +317,13 @@ int wave_trav(const srt_pt* pt) {
 }
 bool wave_kernel_applies(const srt_pt* pt) { return wave_trav(pt) >= 0; }
 
+// Samples per pixel one launch handles: 64, fewer for very large shards so that the per-sample buffer (16 B per
+// sample) stays under 2 GiB.
+uint32_t samples_per_launch(uint32_t px) {
+  const uint64_t fit = px ? (1ull << 27) / px : 64;
+  return (uint32_t)(fit >= 64 ? 64 : (fit < 4 ? 4 : fit));
+}
+
 // One epoch with the wave-uniform persistent kernel: launches of <= 64 samples per pixel, each followed by the
 // ordered per-pixel reduction.
 // Timing brackets for the dominant kernel (srt_pt_kernel_time).
@@ -359,7 +366,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     pt->wave_lds = lds;
     if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_wave_kernel: %d blocks/CU x %d CUs, %zu B LDS per block\n", per_cu, cus, lds);
   }
-  const uint32_t chunk = 64;
+  const uint32_t chunk = samples_per_launch(px);
   const uint32_t nlanes = (uint32_t)pt->wave_blocks * 256;
   int st;
   if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
@@ -413,7 +420,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
 int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
-  const uint32_t chunk = 64;
+  const uint32_t chunk = samples_per_launch(px);
   int st;
   if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;

@@ -290,3 +290,27 @@ def test_zero_samples_and_reuse(srt):
     want = H.OraclePT(pt_scene("cbox_lambertian"), 16, 16, 8, True).epoch(1, 0, 3)
     assert bits_equal(b, want) and not bits_equal(a, b)
     pt.close()
+
+
+def test_large_image_multi_launch(srt):
+    """An image large enough that one launch handles fewer than 64 samples per pixel (the per-sample buffer is capped):
+    4096x2048 at 20 spp = two launches of 16 + 4; 64 random pixels are checked against per-sample radiance from the
+    instrumented kernel, summed in sample order the way do_trace does."""
+    scene = pt_scene("cbox_lambertian")
+    w, h, spp = 4096, 2048, 20
+    pt = make_pt(srt, scene, w, h, 8, True)
+    img = pt.render_epoch(11, 5, spp)
+    rng = np.random.default_rng(0)
+    xs = rng.integers(0, w, 64).astype(np.uint32)
+    ys = rng.integers(0, h, 64).astype(np.uint32)
+    for x, y in zip(xs, ys):
+        rgb, _, _ = pt.trace_samples(11, np.full(spp, x, np.uint32), np.full(spp, y, np.uint32), np.arange(5, 5 + spp, dtype=np.uint32))
+        acc = np.zeros(3, np.float32)
+        n = 0
+        for s in range(spp):
+            if np.isfinite(rgb[s]).all():
+                acc = (acc + rgb[s]).astype(np.float32)
+                n += 1
+        want = (acc * np.float32(1.0 / n)).astype(np.float32) if n else acc
+        assert bits_equal(img[y, x], want), (x, y)
+    pt.close()
