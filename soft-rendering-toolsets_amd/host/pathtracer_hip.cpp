@@ -126,8 +126,30 @@ void Pathtracer::build_scene(Scene& layout_scene) {
                 warned = true;
             }
         } else if(item.is<Scene_Particles>()) {
-            if(!warned) warn("HIP path tracer: particles are not on this path yet; ignored");
-            warned = true;
+            // build_scene, rays/pathtracer.cpp:134-156: one Lambertian copy of the particle mesh per particle,
+            // posed by translate(p.pos) * scale(opt.scale)
+            Scene_Particles& particles = item.get<Scene_Particles>();
+            srt_pt_material mat;
+            std::memset(&mat, 0, sizeof mat);
+            mat.type = SRT_MAT_LAMBERTIAN;
+            const Spectrum albedo = particles.opt.color.to_linear();
+            mat.a[0] = albedo.r; mat.a[1] = albedo.g; mat.a[2] = albedo.b;
+            uint32_t idx = 0;
+            check(srt_pt_add_material(ctx, &mat, &idx), "srt_pt_add_material");
+            const GL::Mesh& mesh = particles.mesh();
+            std::vector<float> pos, nrm;
+            for(const auto& v : mesh.verts()) {
+                pos.insert(pos.end(), {v.pos.x, v.pos.y, v.pos.z});
+                nrm.insert(nrm.end(), {v.norm.x, v.norm.y, v.norm.z});
+            }
+            const auto& idxs = mesh.indices();
+            for(const Scene_Particles::Particle& p : particles.get_particles()) {
+                float T[16];
+                mat_to_array(Mat4::translate(p.pos) * Mat4::scale(Vec3{particles.opt.scale}), T);
+                check(srt_pt_add_mesh(ctx, pos.data(), nrm.data(), (uint32_t)mesh.verts().size(), idxs.data(),
+                                      (uint32_t)idxs.size(), T, idx, 0),
+                      "srt_pt_add_mesh");
+            }
         }
     });
     check(srt_pt_scene_commit(ctx, scene_use_bvh ? 1 : 0), "srt_pt_scene_commit");
