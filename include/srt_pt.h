@@ -81,6 +81,15 @@ int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t 
 #define SRT_LIGHT_SPOT 2u
 int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const float angle_bounds[2], const float trans[16]);
 
+/* The environment light (Pathtracer::env_light, rays/env_light.h): a uniform sphere (Env_Sphere) or upper hemisphere
+ * (Env_Hemisphere) of the given radiance; rays that leave the scene see it, and sample_area_lights /
+ * area_lights_pdf mix it with the area lights as the reference does (a coin flip, the mean of the pdfs).  Image
+ * environment maps (Env_Map) are not on this path.  Scenes with an environment light run on the per-lane kernels. */
+#define SRT_ENV_NONE 0u
+#define SRT_ENV_SPHERE 1u
+#define SRT_ENV_HEMISPHERE 2u
+int srt_pt_set_env_light(srt_pt* pt, uint32_t type, const float radiance[3]);
+
 /* Builds every BVH<Triangle> (leaf size 4) and the BVH<Object> (leaf size 1) exactly as the reference
  * does — or the List<> forms when use_bvh == 0 — flattens them and uploads the scene. */
 int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
@@ -155,6 +164,8 @@ int srt_pt_counters(srt_pt* pt, uint64_t out[8]);
 int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, float* sin_out);
 /* The kernels' atan2f (glibc 2.35's algorithm restated; Spot_Light::sample) evaluated on the device. */
 int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, float* out);
+/* The kernels' acosf (glibc 2.35's algorithm restated; Samplers::Hemisphere::Uniform) evaluated on the device. */
+int srt_pt_math_acos(srt_pt* pt, const float* x, size_t n, float* out);
 
 int srt_pt_sync(srt_pt* pt);
 

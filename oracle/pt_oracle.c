@@ -71,6 +71,7 @@ typedef struct {
     object_t* objs; uint32_t nobjs;
     object_t* lights; uint32_t nlights;
     struct delta_light* dlights; uint32_t ndlights;   /* Pathtracer::point_lights */
+    int env_type; spec env_radiance;                  /* Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere */
     int use_bvh, committed;
     bvh_t tlas;             /* BVH<Object>; tlas.prim = object order after build */
     m4 iview; float vfov, ar;
@@ -224,6 +225,43 @@ static float srt_atan2f(float y, float x) {
     if (m == 2) return pi - (z - pi_lo);
     return (z - pi_lo) - pi;
 }
+/* SRT-MATH v2 acosf: glibc 2.35 __ieee754_acosf (sysdeps/ieee754/flt-32/e_acosf.c) */
+static float srt_acosf(float x) {
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
+                pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f,
+                qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    float z, p, q, r, w, s, c, df;
+    int32_t hx = (int32_t)f_bits(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return (hx > 0) ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+        z = x * x;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (hx < 0) {
+        z = (one + x) * 0.5f;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        s = sqrtf(z);
+        r = p / q;
+        w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    z = (one - x) * 0.5f;
+    s = sqrtf(z);
+    df = bits_f(f_bits(s) & 0xfffff000u);
+    c = (z - df * df) / (s + df);
+    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    r = p / q;
+    w = r * s + c;
+    return 2.0f * (df + w);
+}
+static float m_acos(const scene_t* s, float x) { return s->math_mode ? srt_acosf(x) : acosf(x); }
 static float m_atan2(const scene_t* s, float y, float x) { return s->math_mode ? srt_atan2f(y, x) : atan2f(y, x); }
 
 static float m_cos(const scene_t* s, float x) { return s->math_mode ? srt_cosf(x) : cosf(x); }
@@ -755,8 +793,30 @@ static spec mat_emissive(const material_t* m) { return m->type == MAT_DIFFUSE ? 
  * List::sample/pdf (rays/list.h:43-55), Object::sample/pdf (rays/object.h:77-101),
  * Triangle::sample/pdf (student/tri_mesh.cpp:117-143), Samplers::Triangle (samplers.cpp:143-149)
  * ---------------------------------------------------------------------------------------------- */
-static v3 sample_area_lights(ctx_t* c, v3 from) {
+/* Env_Sphere / Env_Hemisphere::evaluate, student/env_light.cpp:103-118 */
+static spec env_evaluate(const scene_t* s, v3 dir) {
+    if (s->env_type == 2) return (dir.y > 0.0f) ? s->env_radiance : S(0, 0, 0);
+    return s->env_radiance;
+}
+/* Env_*::sample = Samplers::Hemisphere::Uniform::sample, student/samplers.cpp:151-164 (Sphere::Uniform returns the same
+ * upper-hemisphere sample, :17-26) */
+static v3 env_sample(ctx_t* c) {
     const scene_t* s = c->s;
+    float xi1 = rng_unit(c);
+    float xi2 = rng_unit(c);
+    float theta = m_acos(s, xi1);
+    float phi = 2.0f * PI_F * xi2;
+    float xs = m_sin(s, theta) * m_cos(s, phi);
+    float ys = m_cos(s, theta);
+    float zs = m_sin(s, theta) * m_sin(s, phi);
+    return V(xs, ys, zs);
+}
+static v3 sample_area_lights(ctx_t* c, v3 from) {                /* rays/pathtracer.cpp:301-311 */
+    const scene_t* s = c->s;
+    if (s->env_type) {
+        if (!s->nlights) return env_sample(c);
+        if (rng_coin(c, 0.5f)) return env_sample(c);
+    }
     if (!s->nlights) return V(0, 0, 0);
     const object_t* o = &s->lights[rng_integer(c, 0, (int)s->nlights)];
     if (o->has_trans) from = m_point(&o->itrans, from);
@@ -803,6 +863,10 @@ static float area_lights_pdf(ctx_t* c, v3 from, v3 dir) {
             ret += sum / (float)o->ntri;
         }
         pdf += ret / (float)s->nlights;
+        n++;
+    }
+    if (s->env_type) {                          /* Env_Sphere::pdf 1/(4 PI), Env_Hemisphere::pdf 1/(2 PI) */
+        pdf += (s->env_type == 2) ? (1.0f / (2.0f * PI_F)) : (1.0f / (4.0f * PI_F));
         n++;
     }
     if (n) pdf /= n;
@@ -909,7 +973,10 @@ static pair_t pt_trace(ctx_t* c, const ray_t* ray) {
     const scene_t* s = c->s;
     pair_t out = {{0, 0, 0}, {0, 0, 0}};
     trace_t result = scene_hit(c, ray);
-    if (!result.hit) return out;                /* no environment light on this path */
+    if (!result.hit) {                          /* student/pathtracer.cpp:182-188 */
+        if (s->env_type) out.emissive = env_evaluate(s, ray->dir);
+        return out;
+    }
     const material_t* bsdf = &s->mats[result.material];
     if (!mat_sided(bsdf) && v_dot(result.normal, ray->dir) > 0.0f) result.normal = v_neg(result.normal);
     spec emissive = mat_emissive(bsdf);
@@ -1032,6 +1099,15 @@ int srt_oracle_pt_add_light(void* h, uint32_t type, const float radiance[3], con
     l->trans = m_from(T);
     l->itrans = m_inverse(&l->trans);
     l->has_trans = m_ne_identity(&l->trans);
+    return 0;
+}
+
+/* Pathtracer::env_light: 0 none, 1 Env_Sphere(radiance), 2 Env_Hemisphere(radiance) */
+int srt_oracle_pt_set_env_light(void* h, uint32_t type, const float radiance[3]) {
+    scene_t* s = (scene_t*)h;
+    if (s->committed || type > 2) return -1;
+    s->env_type = (int)type;
+    s->env_radiance = type ? S(radiance[0], radiance[1], radiance[2]) : S(0, 0, 0);
     return 0;
 }
 
@@ -1202,6 +1278,10 @@ long srt_oracle_pt_dump_bvh(void* h, int which, float* boxes, uint32_t* links, s
 }
 
 /* cosf/sinf of SRT-MATH v2, exposed so tests can compare them with libm and with the kernel. */
+int srt_oracle_math_acos(const float* x, size_t n, float* out) {
+    for (size_t i = 0; i < n; i++) out[i] = srt_acosf(x[i]);
+    return 0;
+}
 int srt_oracle_math_atan2(const float* y, const float* x, size_t n, float* out) {
     for (size_t i = 0; i < n; i++) out[i] = srt_atan2f(y[i], x[i]);
     return 0;

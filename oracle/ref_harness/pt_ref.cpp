@@ -188,6 +188,18 @@ int ref_pt_add_light(void* h, uint32_t type, const float radiance[3], const floa
   return 0;
 }
 
+// build_lights for an environment light: type 1 Env_Sphere, 2 Env_Hemisphere (uniform radiance), 0 none.
+int ref_pt_set_env_light(void* h, uint32_t type, const float radiance[3]) {
+  RefPT* r = (RefPT*)h;
+  r->pt->env_light.reset();
+  if (type == 0) return 0;
+  const Spectrum rad(radiance[0], radiance[1], radiance[2]);
+  if (type == 1) r->pt->env_light = PT::Env_Light(PT::Env_Sphere(rad));
+  else if (type == 2) r->pt->env_light = PT::Env_Light(PT::Env_Hemisphere(rad));
+  else return -1;
+  return 0;
+}
+
 // Tail of build_scene (rays/pathtracer.cpp:165-175).
 int ref_pt_commit(void* h) {
   RefPT* r = (RefPT*)h;

@@ -24,6 +24,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_scene_begin.argtypes = [c_void_p]
     lib.srt_pt_add_material.argtypes = [c_void_p, POINTER(PtMaterial), POINTER(c_uint32)]
     lib.srt_pt_add_mesh.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_int]
+    lib.srt_pt_set_env_light.argtypes = [c_void_p, c_uint32, c_void_p]
     lib.srt_pt_add_light.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_add_sphere.argtypes = [c_void_p, c_float, c_void_p, c_uint32]
     lib.srt_pt_scene_commit.argtypes = [c_void_p, c_int]
@@ -45,6 +46,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_dump_bvh.restype = c_long
     lib.srt_pt_counters.argtypes = [c_void_p, c_void_p]
     lib.srt_pt_math_cos_sin.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
+    lib.srt_pt_math_acos.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_math_atan2.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_sync.argtypes = [c_void_p]
 
@@ -132,6 +134,9 @@ class Pathtracer:
                                                  int(o["material"]), int(bool(o["is_light"]))))
             else:
                 self._check(L, L.srt_pt_add_sphere(self._ctx, float(o["radius"]), _p(T), int(o["material"])))
+        if d.get("env"):               # environment light: {"type": 1 sphere | 2 hemisphere, "radiance"}
+            rad = _f32(d["env"]["radiance"])
+            self._check(L, L.srt_pt_set_env_light(self._ctx, int(d["env"]["type"]), _p(rad)))
         for l in d.get("lights", []):   # delta lights (Pathtracer::build_lights): type 0 directional, 1 point, 2 spot
             rad, ab, T = _f32(l["radiance"]), _f32(l.get("angle_bounds", (0.0, 0.0))), _f32(l["T"])
             self._check(L, L.srt_pt_add_light(self._ctx, int(l["type"]), _p(rad), _p(ab), _p(T)))
@@ -255,6 +260,12 @@ class Pathtracer:
         if n < 0:
             raise self._SrtError(int(n), self._lib.srt_last_error().decode())
         return boxes[:n].copy(), links[:n].copy(), order
+
+    def math_acos(self, x):
+        x = _f32(x)
+        out = np.zeros(len(x), np.float32)
+        self._check(self._lib, self._lib.srt_pt_math_acos(self._ctx, _p(x), len(x), _p(out)))
+        return out
 
     def math_atan2(self, y, x):
         y, x = _f32(y), _f32(x)

@@ -180,6 +180,11 @@ __global__ void pt_math_kernel(const float* __restrict__ x, size_t n, float* __r
   if (i < n) { c[i] = srt_cosf(x[i]); s[i] = srt_sinf(x[i]); }
 }
 
+__global__ void pt_acos_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = srt_acosf(x[i]);
+}
+
 __global__ void pt_atan2_kernel(const float* __restrict__ y, const float* __restrict__ x, size_t n, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = srt_atan2f(y[i], x[i]);
@@ -210,6 +215,7 @@ struct srt_pt {
   WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr;
   DeltaLight* d_dlights = nullptr;
   std::vector<DeltaLight> delta_lights;   // srt_pt_add_light, in call order
+  uint32_t env_type = 0; float env_radiance[3] = {0, 0, 0};   // srt_pt_set_env_light
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
@@ -261,6 +267,7 @@ DScene device_scene(const srt_pt* pt) {
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
   S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas;
   S.delta_lights = pt->d_dlights; S.ndelta = (uint32_t)F.delta_lights.size();
+  S.env_type = pt->env_type; S.env_radiance[0] = pt->env_radiance[0]; S.env_radiance[1] = pt->env_radiance[1]; S.env_radiance[2] = pt->env_radiance[2];
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.cam = pt->cam; S.w = pt->w; S.h = pt->h; S.max_depth = pt->max_depth;
@@ -305,6 +312,7 @@ int wave_trav(const srt_pt* pt) {
   const int m = pt->kernel_mode;
   if (m == 1 || m == 4) return -1;
   const bool lights = !F.delta_lights.empty();   // point_lighting's shadow batches: sweeps only, not the stamped build
+  if (pt->env_type != 0) return -1;              // environment lights: per-lane kernels only so far
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
   const bool flat_fits = flat_walk_fits(F);
@@ -496,6 +504,7 @@ int srt_pt_scene_begin(srt_pt* pt) {
   pt->inputs.clear();
   pt->materials.clear();
   pt->delta_lights.clear();
+  pt->env_type = 0;
   pt->committed = false;
   return SRT_OK;
 }
@@ -554,6 +563,16 @@ int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const f
   Mat4 T;
   std::memcpy(&T, trans, sizeof(Mat4));
   pt->delta_lights.push_back(make_delta_light(type, radiance, angle_bounds, T));
+  return SRT_OK;
+}
+
+int srt_pt_set_env_light(srt_pt* pt, uint32_t type, const float radiance[3]) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_env_light: NULL context");
+  if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");
+  if (type > SRT_ENV_HEMISPHERE) return srt::fail(SRT_ERR_INVALID, "unknown environment light type %u", type);
+  if (type != SRT_ENV_NONE && !radiance) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_env_light: radiance is NULL");
+  pt->env_type = type;
+  for (int i = 0; i < 3; i++) pt->env_radiance[i] = (type != SRT_ENV_NONE) ? radiance[i] : 0.0f;
   return SRT_OK;
 }
 
@@ -864,6 +883,22 @@ int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, fl
   SRT_HIP(hipMemcpyAsync(sin_out, dsn, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   (void)hipFree(dx); (void)hipFree(dc); (void)hipFree(dsn);
+  return SRT_OK;
+}
+
+int srt_pt_math_acos(srt_pt* pt, const float* x, size_t n, float* out) {
+  int st = need_device(pt, "srt_pt_math_acos");
+  if (st != SRT_OK) return st;
+  if (!x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_acos: NULL argument");
+  if (!n) return SRT_OK;
+  float *dx = nullptr, *dout = nullptr;
+  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
+  pt_acos_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, n, dout);
+  SRT_HIP(hipGetLastError());
+  SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  (void)hipFree(dx); (void)hipFree(dout);
   return SRT_OK;
 }
 

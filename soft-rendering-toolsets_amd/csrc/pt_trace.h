@@ -26,6 +26,8 @@ struct DScene {
   const WaveInterior* blas_recs;   // interior records of every BVH<Triangle>
   const DeltaLight* delta_lights;  // Pathtracer::point_lights
   uint32_t ndelta;
+  uint32_t env_type;               // Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere (uniform radiance)
+  float env_radiance[3];
   uint32_t wave_q;
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
@@ -410,9 +412,32 @@ SRT_DEV Scatter scatter(const Material& m, V3 out, Rng& rng) {
 }
 SRT_DEV Spec emissive_of(const Material& m) { return m.type == 3 ? spec(m.a[0], m.a[1], m.a[2]) : spec(0, 0, 0); }
 
-// Pathtracer::sample_area_lights (no environment light on this path): List<Object>::sample ->
-// Object::sample -> List<Triangle>::sample -> Samplers::Triangle::sample.
+// Env_Sphere / Env_Hemisphere::evaluate (student/env_light.cpp:103-118).
+SRT_DEV Spec env_evaluate(const DScene& S, V3 dir) {
+  const Spec r = spec(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+  if (S.env_type == 2u) return (dir.y > 0.0f) ? r : spec(0, 0, 0);
+  return r;
+}
+// Env_*::sample = Samplers::Hemisphere::Uniform::sample (student/samplers.cpp:151-164; Sphere::Uniform returns the
+// same upper-hemisphere sample, :17-26): two draws.
+SRT_DEV V3 env_sample(Rng& rng) {
+  const float xi1 = rng.unit();
+  const float xi2 = rng.unit();
+  const float theta = srt_acosf(xi1);
+  const float phi = 2.0f * kPi * xi2;
+  float ct, st, cp, sp;
+  srt_sincosf2(theta, ct, st);
+  srt_sincosf2(phi, cp, sp);
+  return v3(st * cp, ct, st * sp);
+}
+
+// Pathtracer::sample_area_lights (rays/pathtracer.cpp:301-311): List<Object>::sample -> Object::sample ->
+// List<Triangle>::sample -> Samplers::Triangle::sample; with an environment light a coin picks between the two.
 SRT_DEV V3 light_sample(const DScene& S, V3 from, Rng& rng) {
+  if (S.env_type != 0u) {
+    if (S.nlights == 0) return env_sample(rng);
+    if (rng.coin(0.5f)) return env_sample(rng);
+  }
   if (S.nlights == 0) return v3(0, 0, 0);
   const Light& L = S.lights[rng.integer(0, (int)S.nlights)];
   if (L.has_trans) from = mat_point(L.itrans, from);
@@ -462,6 +487,10 @@ SRT_DEV float light_pdf(const DScene& S, V3 from, V3 dir, Counters& cnt) {
     pdf += ret / (float)S.nlights;
     n++;
   }
+  if (S.env_type != 0u) {                          // Env_Sphere::pdf = 1 / (4 PI), Env_Hemisphere::pdf = 1 / (2 PI)
+    pdf += (S.env_type == 2u) ? (1.0f / (2.0f * kPi)) : (1.0f / (4.0f * kPi));
+    n++;
+  }
   if (n) pdf /= n;
   return pdf;
 }
@@ -483,7 +512,7 @@ SRT_DEV Ray camera_ray(const DScene& S, float sx, float sy) { return camera_ray(
 template <bool COUNT>
 SRT_DEV Spec emitted_along(const DScene& S, const Ray& ray, Counters& cnt) {
   const Hit h = scene_hit<COUNT>(S, ray, cnt);
-  if (!h.hit) return spec(0, 0, 0);
+  if (!h.hit) return (S.env_type != 0u) ? env_evaluate(S, ray.d) : spec(0, 0, 0);   // student/pathtracer.cpp:182-188
   const Spec e = emissive_of(S.materials[S.objects[h.obj].material]);
   return (luma(e) > 0.0f) ? e : spec(0, 0, 0);
 }
@@ -543,7 +572,10 @@ SRT_DEV Spec path_sample(const DScene& S, uint32_t x, uint32_t y, Rng& rng, Coun
   int level = 0;
   for (;;) {
     const Hit h = scene_hit<COUNT>(S, ray, cnt);
-    if (!h.hit) break;
+    if (!h.hit) {                                   // {env_light.evaluate(ray.dir), {}}: only a camera ray's `.first` is used
+      if (level == 0 && S.env_type != 0u) emissive_cam = env_evaluate(S, ray.d);
+      break;
+    }
     const Material& m = S.materials[S.objects[h.obj].material];
     const Spec e = emissive_of(m);
     if (luma(e) > 0.0f) { if (level == 0) emissive_cam = e; break; }

@@ -121,9 +121,19 @@ void Pathtracer::build_scene(Scene& layout_scene) {
             case Light_Type::spot:
                 check(srt_pt_add_light(ctx, SRT_LIGHT_SPOT, rad, ab, pose.data), "srt_pt_add_light");
                 break;
-            default:   // sphere / hemisphere / rectangle: environment lights (Env_Light) are not on this path yet
-                if(!warned) warn("HIP path tracer: environment lights are not on this path yet; ignored");
-                warned = true;
+            case Light_Type::sphere:
+                if(light.opt.has_emissive_map) {   // Env_Map: image environment maps are not on this path yet
+                    if(!warned) warn("HIP path tracer: image environment maps are not on this path yet; ignored");
+                    warned = true;
+                } else {
+                    check(srt_pt_set_env_light(ctx, SRT_ENV_SPHERE, rad), "srt_pt_set_env_light");
+                }
+                break;
+            case Light_Type::hemisphere:
+                check(srt_pt_set_env_light(ctx, SRT_ENV_HEMISPHERE, rad), "srt_pt_set_env_light");
+                break;
+            default:
+                break;
             }
         } else if(item.is<Scene_Particles>()) {
             // build_scene, rays/pathtracer.cpp:134-156: one Lambertian copy of the particle mesh per particle,

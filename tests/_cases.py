@@ -157,6 +157,18 @@ def pt_scene(name):
             {"type": 1, "radiance": np.array([0.2, 0.2, 0.2], np.float32), "T": np.eye(4, dtype=np.float32).reshape(16)},   # at the origin, no transform
         ]
         return s
+    if name in ("cbox_envsphere", "cbox_envhemi", "cbox_envonly"):
+        # an open Cornell box (no ceiling, no back wall) under an environment light, so that rays escape:
+        # uniform sphere + the area light (coin-flipped sampling, mean of the pdfs); hemisphere + the area light;
+        # hemisphere alone (sample_area_lights always samples the environment)
+        s = scenes.cornell_box("cbox")
+        keep = [o for o in s["objects"] if not (o["kind"] == "mesh" and not o["is_light"] and
+                                                 (np.asarray(o["T"], np.float32).reshape(4, 4).T @ np.array([0, 0, 0, 1], np.float32))[1] > 0.95)]
+        s["objects"] = keep[:1] + keep[2:] if len(keep) == len(s["objects"]) else keep   # make sure something is removed
+        if name == "cbox_envonly":
+            s["objects"] = [o for o in s["objects"] if not (o["kind"] == "mesh" and o["is_light"])]
+        s["env"] = {"type": 1 if name == "cbox_envsphere" else 2, "radiance": np.array([0.7, 0.8, 1.0], np.float32)}
+        return s
     if name == "cbox_nolight":
         s = scenes.cornell_box("cbox_lambertian")
         s["objects"] = s["objects"][:-1]   # no area light: sample_area_lights returns the zero vector -> NaN rays
@@ -178,6 +190,8 @@ def scene_digest(scene):
                      + np.asarray(o["idx"], np.uint32).tobytes() + bytes([int(o["is_light"])]))
         else:
             h.update(np.asarray([o["radius"]], np.float32).tobytes())
+    if scene.get("env"):
+        h.update(np.asarray([scene["env"]["type"]], np.int32).tobytes() + np.asarray(scene["env"]["radiance"], np.float32).tobytes())
     for l in scene.get("lights", []):
         h.update(np.asarray([l["type"]], np.int32).tobytes() + np.asarray(l["radiance"], np.float32).tobytes()
                  + np.asarray(l.get("angle_bounds", (0.0, 0.0)), np.float32).tobytes() + np.asarray(l["T"], np.float32).tobytes())

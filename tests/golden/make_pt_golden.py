@@ -37,6 +37,9 @@ CASES = [
     ("cbox_nolight", 32, 32, 4, True, 1024, (16, 16, 4)),       # empty area-light list -> every sample invalid
     ("cbox_deltalights", 48, 40, 8, True, 3072, (24, 20, 8)),   # point + spot + directional lights: point_lighting's shadow rays
     ("cbox_deltalights", 32, 24, 4, False, 1024, None),
+    ("cbox_envsphere", 40, 32, 8, True, 2048, (20, 16, 8)),     # Env_Sphere + area light: coin-flipped sampling, mean of the pdfs
+    ("cbox_envhemi", 32, 24, 5, True, 1024, None),              # Env_Hemisphere: radiance only for dir.y > 0
+    ("cbox_envonly", 32, 24, 8, False, 1024, (16, 12, 4)),      # environment light alone (no area lights)
 ]
 SEED = 20260331
 

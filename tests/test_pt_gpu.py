@@ -143,6 +143,36 @@ def test_delta_lights(srt):
     pt.close()
 
 
+@pytest.mark.parametrize("name", ["cbox_envsphere", "cbox_envhemi", "cbox_envonly"])
+def test_environment_lights(srt, name):
+    """Env_Sphere / Env_Hemisphere: rays that leave the scene, sample_area_lights' coin flip, area_lights_pdf's mean -
+    per-lane kernels against the oracle; the wave kernel refuses the scene instead of ignoring the light."""
+    scene = pt_scene(name)
+    w, h, spp = 36, 28, 4
+    want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
+    pt = make_pt(srt, scene, w, h, 8, True)
+    for mode in (0, 1, 4):
+        pt.set_kernel(mode)
+        assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
+    for mode in (2, 5):
+        pt.set_kernel(mode)
+        with pytest.raises(srt.SrtError):
+            pt.render_epoch(8, 1, spp)
+    pt.close()
+
+
+def test_kernel_math_is_glibc_acosf(srt):
+    pt = srt.Pathtracer(0)
+    x = np.concatenate([np.random.default_rng(3).random(300000, dtype=np.float32) * 2 - 1,
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.49999997, 1e-20, 1.5, np.nan], np.float32)])
+    got = pt.math_acos(x)
+    import ctypes
+    want = np.zeros_like(x)
+    H.oracle().srt_oracle_math_acos(H.P(x), ctypes.c_size_t(len(x)), H.P(want))
+    assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+    pt.close()
+
+
 def test_epoch_image_and_tiling(srt):
     """cfg3-shaped run at reduced size: epoch images equal the oracle's; sharding the image over 1, 2 and 3
     ranks (tile round-robin) produces the same pixels; the device untile + accumulate path equals the host one."""

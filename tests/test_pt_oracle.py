@@ -115,6 +115,21 @@ def test_srt_math_atan2_is_glibc():
         assert out[i].view(np.uint32) == want.view(np.uint32) or (np.isnan(out[i]) and np.isnan(want)), (float(y[i]), float(x[i]))
 
 
+def test_srt_math_acos_is_glibc():
+    """SRT-MATH v2's acosf restates glibc 2.35's __ieee754_acosf (Samplers::Hemisphere::Uniform): bit-identical to libm."""
+    x = np.concatenate([np.random.default_rng(4).random(200000, dtype=np.float32) * 2 - 1,
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 0.49999997, 1e-20, 0.99999994, -0.99999994], np.float32)])
+    out = np.zeros_like(x)
+    H.oracle().srt_oracle_math_acos(H.P(x), ctypes.c_size_t(len(x)), H.P(out))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.acosf.restype = ctypes.c_float
+    libm.acosf.argtypes = [ctypes.c_float]
+    idx = np.random.default_rng(5).integers(0, len(x), 30000)
+    idx[:10] = np.arange(len(x) - 10, len(x))
+    for i in idx:
+        assert out[i].view(np.uint32) == np.float32(libm.acosf(float(x[i]))).view(np.uint32), float(x[i])
+
+
 def test_accumulate_running_mean():
     rng = np.random.default_rng(3)
     acc = np.zeros(300, np.float32)
