@@ -84,7 +84,7 @@ int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const f
 /* The environment light (Pathtracer::env_light, rays/env_light.h): a uniform sphere (Env_Sphere) or upper hemisphere
  * (Env_Hemisphere) of the given radiance; rays that leave the scene see it, and sample_area_lights /
  * area_lights_pdf mix it with the area lights as the reference does (a coin flip, the mean of the pdfs).  Image
- * environment maps (Env_Map) are not on this path.  Scenes with an environment light run on the per-lane kernels. */
+ * environment maps (Env_Map) are not on this path. */
 #define SRT_ENV_NONE 0u
 #define SRT_ENV_SPHERE 1u
 #define SRT_ENV_HEMISPHERE 2u

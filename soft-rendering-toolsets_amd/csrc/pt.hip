@@ -311,8 +311,8 @@ int wave_trav(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   const int m = pt->kernel_mode;
   if (m == 1 || m == 4) return -1;
-  const bool lights = !F.delta_lights.empty();   // point_lighting's shadow batches: sweeps only, not the stamped build
-  if (pt->env_type != 0) return -1;              // environment lights: per-lane kernels only so far
+  // delta lights (point_lighting's shadow batches) and environment lights: the sweeps' DL instantiation only
+  const bool lights = !F.delta_lights.empty() || pt->env_type != 0;
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
   const bool flat_fits = flat_walk_fits(F);
@@ -360,7 +360,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const bool stamp = pt->kernel_mode == 3;
   const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
   const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * 6 * 64 * sizeof(float);  // 4 waves x (Q - 1) x 3 rays x 2 fields
-  const bool dl = !F.delta_lights.empty();
+  const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
   const void* kern = stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false> : (const void*)pt_wave_kernel<true, 2, false>)
                      : dl  ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, true> : (const void*)pt_wave_kernel<false, 1, true>)
                            : (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<false, 1, false> : (const void*)pt_wave_kernel<false, 2, false>);

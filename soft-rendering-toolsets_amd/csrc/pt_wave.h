@@ -206,6 +206,7 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
 }
 
 constexpr uint32_t kRetMiss = 0xFFFFFFFFu;
+constexpr uint32_t kRetMissEnv = 0xFFFFFFFEu;   // miss, and the environment light is visible along the (camera) ray
 SRT_DEV uint32_t pack_ret(const Hit& h) { return h.hit ? ((h.obj << 27) | h.tri) : kRetMiss; }
 SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
   Hit h;
@@ -517,11 +518,20 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
         chit = pack_ret(res[0]);
         pend[0] = pack_ret(res[1]);
         pend[1] = pack_ret(res[2]);
+        if (DL && S.env_type != 0u) {
+          // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
+          // whether evaluate(dir) is the radiance or zero, the directions are gone when the parked samples are resolved
+          if (!res[0].hit && (S.env_type == 1u || d[0].y > 0.0f)) chit = kRetMissEnv;
+          if (!res[1].hit && (S.env_type == 1u || d[1].y > 0.0f)) pend[0] = kRetMissEnv;
+          if (!res[2].hit && (S.env_type == 1u || d[2].y > 0.0f)) pend[1] = kRetMissEnv;
+        }
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
           Spec eA = spec(0, 0, 0), eB = spec(0, 0, 0);
           if (res[0].hit) { const Spec e = emissive_of(S.materials[S.objects[res[0].obj].material]); if (luma(e) > 0.0f) eA = e; }
+          else if (DL && S.env_type != 0u) eA = env_evaluate(S, d[0]);
           if (actB && res[1].hit) { const Spec e = emissive_of(S.materials[S.objects[res[1].obj].material]); if (luma(e) > 0.0f) eB = e; }
+          else if (DL && actB && S.env_type != 0u) eB = env_evaluate(S, d[1]);
           Spec radiance = spec(0, 0, 0);
           if (discrete) {
             const Spec direct = eA * att;
@@ -566,9 +576,11 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
       Spec e = spec(0, 0, 0);
       uint32_t mi = 0;
       for (int guard = 0; guard < 3 && !need_shade && alive && !(DL && more_shadow); guard++) {
-        const Hit ch = unpack_ret(0.0f, chit);
+        const bool miss_env = DL && chit == kRetMissEnv;   // a camera ray that left the scene into the environment light
+        const Hit ch = unpack_ret(0.0f, miss_env ? kRetMiss : chit);
         bool terminal = !ch.hit;                         // student/pathtracer.cpp:174-218
         e = spec(0, 0, 0);
+        if (miss_env && level == 0) e = spec(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
         if (!terminal) {
           mi = (uint32_t)S.objects[ch.obj].material;
           e = emissive_of(S.materials[mi]);

@@ -146,15 +146,16 @@ def test_delta_lights(srt):
 @pytest.mark.parametrize("name", ["cbox_envsphere", "cbox_envhemi", "cbox_envonly"])
 def test_environment_lights(srt, name):
     """Env_Sphere / Env_Hemisphere: rays that leave the scene, sample_area_lights' coin flip, area_lights_pdf's mean -
-    per-lane kernels against the oracle; the wave kernel refuses the scene instead of ignoring the light."""
+    per-lane kernels and the wave kernel against the oracle; the builds without environment lights (flattened walk,
+    stamped) refuse the scene instead of ignoring the light."""
     scene = pt_scene(name)
-    w, h, spp = 36, 28, 4
+    w, h, spp = 36, 28, 7
     want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
     pt = make_pt(srt, scene, w, h, 8, True)
-    for mode in (0, 1, 4):
+    for mode in (0, 1, 2, 4):
         pt.set_kernel(mode)
         assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
-    for mode in (2, 5):
+    for mode in (3, 5):
         pt.set_kernel(mode)
         with pytest.raises(srt.SrtError):
             pt.render_epoch(8, 1, spp)
