@@ -83,12 +83,16 @@ int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const f
 
 /* The environment light (Pathtracer::env_light, rays/env_light.h): a uniform sphere (Env_Sphere) or upper hemisphere
  * (Env_Hemisphere) of the given radiance; rays that leave the scene see it, and sample_area_lights /
- * area_lights_pdf mix it with the area lights as the reference does (a coin flip, the mean of the pdfs).  Image
- * environment maps (Env_Map) are not on this path. */
+ * area_lights_pdf mix it with the area lights as the reference does (a coin flip, the mean of the pdfs). */
 #define SRT_ENV_NONE 0u
 #define SRT_ENV_SPHERE 1u
 #define SRT_ENV_HEMISPHERE 2u
 int srt_pt_set_env_light(srt_pt* pt, uint32_t type, const float radiance[3]);
+/* Env_Map (an HDR_Image as environment): rgb = width * height * 3 floats, pixel (x, y) at index y * width + x as in
+ * HDR_Image::at.  As in the reference fork, directions are sampled uniformly (pdf 1 / 4 PI) and Env_Map::evaluate
+ * looks the image up bilinearly (student/env_light.cpp:7-93).  Per-lane kernels only. */
+#define SRT_ENV_MAP 3u
+int srt_pt_set_env_map(srt_pt* pt, uint32_t width, uint32_t height, const float* rgb);
 
 /* Builds every BVH<Triangle> (leaf size 4) and the BVH<Object> (leaf size 1) exactly as the reference
  * does — or the List<> forms when use_bvh == 0 — flattens them and uploads the scene. */

@@ -71,7 +71,8 @@ typedef struct {
     object_t* objs; uint32_t nobjs;
     object_t* lights; uint32_t nlights;
     struct delta_light* dlights; uint32_t ndlights;   /* Pathtracer::point_lights */
-    int env_type; spec env_radiance;                  /* Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere */
+    int env_type; spec env_radiance;                  /* Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere, 3 Env_Map */
+    float* env_map; uint32_t env_w, env_h;            /* Env_Map: HDR_Image pixels, index y * w + x */
     int use_bvh, committed;
     bvh_t tlas;             /* BVH<Object>; tlas.prim = object order after build */
     m4 iview; float vfov, ar;
@@ -793,8 +794,42 @@ static spec mat_emissive(const material_t* m) { return m->type == MAT_DIFFUSE ? 
  * List::sample/pdf (rays/list.h:43-55), Object::sample/pdf (rays/object.h:77-101),
  * Triangle::sample/pdf (student/tri_mesh.cpp:117-143), Samplers::Triangle (samplers.cpp:143-149)
  * ---------------------------------------------------------------------------------------------- */
-/* Env_Sphere / Env_Hemisphere::evaluate, student/env_light.cpp:103-118 */
+static float std_clamp(float v, float lo, float hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }   /* std::clamp */
+static spec lerp_spec(float ratio, spec a, spec b) {           /* lerpSpectrum, student/env_light.cpp:33-35 */
+    float om = 1 - ratio;
+    return S(om * a.r + ratio * b.r, om * a.g + ratio * b.g, om * a.b + ratio * b.b);
+}
+/* HDR_Image::at(x, y); float -> int conversions that are undefined / assert in the reference are clamped into the image */
+static spec env_texel(const scene_t* s, float x, float y) {
+    int xi = (x >= 0.0f && x < 2147483648.0f) ? (int)x : 0, yi = (y >= 0.0f && y < 2147483648.0f) ? (int)y : 0;
+    if (xi >= (int)s->env_w) xi = (int)s->env_w - 1;
+    if (yi >= (int)s->env_h) yi = (int)s->env_h - 1;
+    const float* p = s->env_map + 3 * ((size_t)yi * s->env_w + (size_t)xi);
+    return S(p[0], p[1], p[2]);
+}
+/* Env_Map::evaluate, student/env_light.cpp:37-93 */
+static spec env_map_evaluate(const scene_t* s, v3 dir) {
+    float r = v_norm(dir);
+    float theta = PI_F - m_acos(s, dir.y / r);
+    float phi = m_atan2(s, dir.z, dir.x);
+    if (phi < 0) phi = phi + 2.f * PI_F;
+    theta = std_clamp(theta / PI_F, 0.f, 1.f);
+    phi = std_clamp(phi / (2.0f * PI_F), 0.f, 1.f);
+    float h = (float)s->env_h, w = (float)s->env_w;
+    float u = phi * w, v = theta * h;
+    float u0 = floorf(u), v0 = floorf(v), u1, v1, t;
+    if (u - u0 < 0.5f) { u1 = u0 - 1; t = u0; u0 = u1; u1 = t; } else { u1 = u0 + 1.f; }
+    if (v - v0 < 0.5f) { v1 = v0 - 1; t = v0; v0 = v1; v1 = t; } else { v1 = v0 + 1.f; }
+    u0 = min_f(max_f(u0, 0.f), w - 1.f); u1 = min_f(max_f(u1, 0.f), w - 1.f);
+    v0 = min_f(max_f(v0, 0.f), h - 1.f); v1 = min_f(max_f(v1, 0.f), h - 1.f);
+    float ru = min_f(max_f(u - u0 - 0.5f, 0.f), 1.f), rv = min_f(max_f(v - v0 - 0.5f, 0.f), 1.f);
+    spec h1 = lerp_spec(ru, env_texel(s, u0, v0), env_texel(s, u1, v0));
+    spec h2 = lerp_spec(ru, env_texel(s, u0, v1), env_texel(s, u1, v1));
+    return lerp_spec(rv, h1, h2);
+}
+/* Env_Sphere / Env_Hemisphere / Env_Map::evaluate, student/env_light.cpp:37-118 */
 static spec env_evaluate(const scene_t* s, v3 dir) {
+    if (s->env_type == 3) return env_map_evaluate(s, dir);
     if (s->env_type == 2) return (dir.y > 0.0f) ? s->env_radiance : S(0, 0, 0);
     return s->env_radiance;
 }
@@ -1108,6 +1143,18 @@ int srt_oracle_pt_set_env_light(void* h, uint32_t type, const float radiance[3])
     if (s->committed || type > 2) return -1;
     s->env_type = (int)type;
     s->env_radiance = type ? S(radiance[0], radiance[1], radiance[2]) : S(0, 0, 0);
+    return 0;
+}
+
+/* Env_Map(image): rgb = w * h * 3 floats, pixel (x, y) at y * w + x */
+int srt_oracle_pt_set_env_map(void* h, uint32_t w, uint32_t hh, const float* rgb) {
+    scene_t* s = (scene_t*)h;
+    if (s->committed || !w || !hh || !rgb) return -1;
+    free(s->env_map);
+    s->env_map = (float*)malloc(sizeof(float) * 3 * (size_t)w * hh);
+    if (!s->env_map) return -1;
+    memcpy(s->env_map, rgb, sizeof(float) * 3 * (size_t)w * hh);
+    s->env_w = w; s->env_h = hh; s->env_type = 3;
     return 0;
 }
 

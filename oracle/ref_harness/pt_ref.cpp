@@ -200,6 +200,15 @@ int ref_pt_set_env_light(void* h, uint32_t type, const float radiance[3]) {
   return 0;
 }
 
+// Env_Map from raw pixels (HDR_Image::at(x, y) = pixels[y * w + x]).
+int ref_pt_set_env_map(void* h, uint32_t w, uint32_t hh, const float* rgb) {
+  RefPT* r = (RefPT*)h;
+  HDR_Image img(w, hh);
+  for (size_t i = 0; i < (size_t)w * hh; i++) img.at(i) = Spectrum(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+  r->pt->env_light = PT::Env_Light(PT::Env_Map(std::move(img)));
+  return 0;
+}
+
 // Tail of build_scene (rays/pathtracer.cpp:165-175).
 int ref_pt_commit(void* h) {
   RefPT* r = (RefPT*)h;

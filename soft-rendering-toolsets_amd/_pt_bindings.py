@@ -25,6 +25,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_add_material.argtypes = [c_void_p, POINTER(PtMaterial), POINTER(c_uint32)]
     lib.srt_pt_add_mesh.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_int]
     lib.srt_pt_set_env_light.argtypes = [c_void_p, c_uint32, c_void_p]
+    lib.srt_pt_set_env_map.argtypes = [c_void_p, c_uint32, c_uint32, c_void_p]
     lib.srt_pt_add_light.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_add_sphere.argtypes = [c_void_p, c_float, c_void_p, c_uint32]
     lib.srt_pt_scene_commit.argtypes = [c_void_p, c_int]
@@ -134,9 +135,13 @@ class Pathtracer:
                                                  int(o["material"]), int(bool(o["is_light"]))))
             else:
                 self._check(L, L.srt_pt_add_sphere(self._ctx, float(o["radius"]), _p(T), int(o["material"])))
-        if d.get("env"):               # environment light: {"type": 1 sphere | 2 hemisphere, "radiance"}
-            rad = _f32(d["env"]["radiance"])
-            self._check(L, L.srt_pt_set_env_light(self._ctx, int(d["env"]["type"]), _p(rad)))
+        if d.get("env"):               # {"type": 1 sphere | 2 hemisphere, "radiance"} or {"type": 3, "image": float32 [h, w, 3]}
+            if int(d["env"]["type"]) == 3:
+                img = _f32(d["env"]["image"])
+                self._check(L, L.srt_pt_set_env_map(self._ctx, img.shape[1], img.shape[0], _p(img)))
+            else:
+                rad = _f32(d["env"]["radiance"])
+                self._check(L, L.srt_pt_set_env_light(self._ctx, int(d["env"]["type"]), _p(rad)))
         for l in d.get("lights", []):   # delta lights (Pathtracer::build_lights): type 0 directional, 1 point, 2 spot
             rad, ab, T = _f32(l["radiance"]), _f32(l.get("angle_bounds", (0.0, 0.0))), _f32(l["T"])
             self._check(L, L.srt_pt_add_light(self._ctx, int(l["type"]), _p(rad), _p(ab), _p(T)))

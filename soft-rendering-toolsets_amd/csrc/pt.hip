@@ -216,6 +216,7 @@ struct srt_pt {
   DeltaLight* d_dlights = nullptr;
   std::vector<DeltaLight> delta_lights;   // srt_pt_add_light, in call order
   uint32_t env_type = 0; float env_radiance[3] = {0, 0, 0};   // srt_pt_set_env_light
+  std::vector<float> env_map; uint32_t env_w = 0, env_h = 0; float* d_env_map = nullptr;   // srt_pt_set_env_map
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
@@ -267,6 +268,7 @@ DScene device_scene(const srt_pt* pt) {
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
   S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas;
   S.delta_lights = pt->d_dlights; S.ndelta = (uint32_t)F.delta_lights.size();
+  S.env_map = pt->d_env_map; S.env_w = pt->env_w; S.env_h = pt->env_h;
   S.env_type = pt->env_type; S.env_radiance[0] = pt->env_radiance[0]; S.env_radiance[1] = pt->env_radiance[1]; S.env_radiance[2] = pt->env_radiance[2];
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
@@ -313,6 +315,7 @@ int wave_trav(const srt_pt* pt) {
   if (m == 1 || m == 4) return -1;
   // delta lights (point_lighting's shadow batches) and environment lights: the sweeps' DL instantiation only
   const bool lights = !F.delta_lights.empty() || pt->env_type != 0;
+  if (pt->env_type == SRT_ENV_MAP) return -1;   // image environment maps: per-lane kernels only
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
   const bool flat_fits = flat_walk_fits(F);
@@ -488,7 +491,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipSetDevice(pt->device);
     (void)hipStreamSynchronize(pt->stream);
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
-    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_dlights);
+    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
     for (auto& v : {&pt->timed, &pt->spare})
@@ -505,6 +508,7 @@ int srt_pt_scene_begin(srt_pt* pt) {
   pt->materials.clear();
   pt->delta_lights.clear();
   pt->env_type = 0;
+  pt->env_map.clear(); pt->env_w = pt->env_h = 0;
   pt->committed = false;
   return SRT_OK;
 }
@@ -569,10 +573,20 @@ int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const f
 int srt_pt_set_env_light(srt_pt* pt, uint32_t type, const float radiance[3]) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_env_light: NULL context");
   if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");
-  if (type > SRT_ENV_HEMISPHERE) return srt::fail(SRT_ERR_INVALID, "unknown environment light type %u", type);
+  if (type > SRT_ENV_HEMISPHERE) return srt::fail(SRT_ERR_INVALID, "unknown environment light type %u (image maps: srt_pt_set_env_map)", type);
   if (type != SRT_ENV_NONE && !radiance) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_env_light: radiance is NULL");
   pt->env_type = type;
   for (int i = 0; i < 3; i++) pt->env_radiance[i] = (type != SRT_ENV_NONE) ? radiance[i] : 0.0f;
+  return SRT_OK;
+}
+
+int srt_pt_set_env_map(srt_pt* pt, uint32_t width, uint32_t height, const float* rgb) {
+  if (!pt || !rgb) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_env_map: NULL argument");
+  if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");
+  if (!width || !height || (uint64_t)width * height > (1ull << 28)) return srt::fail(SRT_ERR_INVALID, "environment map size %ux%u", width, height);
+  pt->env_type = SRT_ENV_MAP;
+  pt->env_w = width; pt->env_h = height;
+  pt->env_map.assign(rgb, rgb + 3 * (size_t)width * height);
   return SRT_OK;
 }
 
@@ -593,7 +607,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
         (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
         (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)) ||
-        (st = upload(&pt->d_dlights, F.delta_lights)))
+        (st = upload(&pt->d_dlights, F.delta_lights)) || (st = upload(&pt->d_env_map, pt->env_map)))
       return st;
   }
   pt->committed = true;

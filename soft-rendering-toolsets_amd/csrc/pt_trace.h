@@ -26,8 +26,10 @@ struct DScene {
   const WaveInterior* blas_recs;   // interior records of every BVH<Triangle>
   const DeltaLight* delta_lights;  // Pathtracer::point_lights
   uint32_t ndelta;
-  uint32_t env_type;               // Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere (uniform radiance)
+  uint32_t env_type;               // Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere (uniform radiance), 3 Env_Map
   float env_radiance[3];
+  const float* env_map;            // Env_Map: HDR_Image pixels, 3 floats per pixel, index y * w + x
+  uint32_t env_w, env_h;
   uint32_t wave_q;
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
@@ -412,8 +414,44 @@ SRT_DEV Scatter scatter(const Material& m, V3 out, Rng& rng) {
 }
 SRT_DEV Spec emissive_of(const Material& m) { return m.type == 3 ? spec(m.a[0], m.a[1], m.a[2]) : spec(0, 0, 0); }
 
-// Env_Sphere / Env_Hemisphere::evaluate (student/env_light.cpp:103-118).
+SRT_DEV float std_clamp(float v, float lo, float hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }   // std::clamp
+SRT_DEV Spec lerp_spec(float ratio, Spec a, Spec b) {      // lerpSpectrum (student/env_light.cpp:33-35): (1 - ratio) * start + ratio * ends
+  const float om = 1 - ratio;
+  return spec(om * a.r + ratio * b.r, om * a.g + ratio * b.g, om * a.b + ratio * b.b);
+}
+// HDR_Image::at(x, y) on the environment map; the float -> int conversions of the reference (x86: INT_MIN for NaN / out
+// of range, an assert there) are clamped into the image here.
+SRT_DEV Spec env_texel(const DScene& S, float x, float y) {
+  int xi = (x >= 0.0f && x < 2147483648.0f) ? (int)x : 0, yi = (y >= 0.0f && y < 2147483648.0f) ? (int)y : 0;
+  xi = xi < (int)S.env_w ? xi : (int)S.env_w - 1;
+  yi = yi < (int)S.env_h ? yi : (int)S.env_h - 1;
+  const float* p = S.env_map + 3 * ((size_t)yi * S.env_w + (size_t)xi);
+  return spec(p[0], p[1], p[2]);
+}
+// Env_Map::evaluate (student/env_light.cpp:37-93): direction -> (theta, phi) -> bilinear lookup as the fork does it.
+SRT_DEV Spec env_map_evaluate(const DScene& S, V3 dir) {
+  const float r = norm(dir);
+  float theta = kPi - srt_acosf(dir.y / r);
+  float phi = srt_atan2f(dir.z, dir.x);
+  if (phi < 0) phi = phi + 2.f * kPi;
+  theta = std_clamp(theta / kPi, 0.f, 1.f);
+  phi = std_clamp(phi / (2.0f * kPi), 0.f, 1.f);
+  const float h = (float)S.env_h, w = (float)S.env_w;
+  const float u = phi * w, v = theta * h;
+  float u0 = floorf(u), v0 = floorf(v), u1, v1;
+  if (u - u0 < 0.5f) { u1 = u0; u0 = u0 - 1; } else { u1 = u0 + 1.f; }     // u1 = u0 - 1; swap(u0, u1)
+  if (v - v0 < 0.5f) { v1 = v0; v0 = v0 - 1; } else { v1 = v0 + 1.f; }
+  u0 = std_min(std_max(u0, 0.f), w - 1.f); u1 = std_min(std_max(u1, 0.f), w - 1.f);   // clamp(): min(max(x, lo), hi)
+  v0 = std_min(std_max(v0, 0.f), h - 1.f); v1 = std_min(std_max(v1, 0.f), h - 1.f);
+  const float ru = std_min(std_max(u - u0 - 0.5f, 0.f), 1.f), rv = std_min(std_max(v - v0 - 0.5f, 0.f), 1.f);
+  const Spec h1 = lerp_spec(ru, env_texel(S, u0, v0), env_texel(S, u1, v0));
+  const Spec h2 = lerp_spec(ru, env_texel(S, u0, v1), env_texel(S, u1, v1));
+  return lerp_spec(rv, h1, h2);
+}
+
+// Env_Sphere / Env_Hemisphere / Env_Map::evaluate (student/env_light.cpp:37-118).
 SRT_DEV Spec env_evaluate(const DScene& S, V3 dir) {
+  if (S.env_type == 3u) return env_map_evaluate(S, dir);
   const Spec r = spec(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
   if (S.env_type == 2u) return (dir.y > 0.0f) ? r : spec(0, 0, 0);
   return r;

@@ -122,9 +122,15 @@ void Pathtracer::build_scene(Scene& layout_scene) {
                 check(srt_pt_add_light(ctx, SRT_LIGHT_SPOT, rad, ab, pose.data), "srt_pt_add_light");
                 break;
             case Light_Type::sphere:
-                if(light.opt.has_emissive_map) {   // Env_Map: image environment maps are not on this path yet
-                    if(!warned) warn("HIP path tracer: image environment maps are not on this path yet; ignored");
-                    warned = true;
+                if(light.opt.has_emissive_map) {   // Env_Map(light.emissive_copy())
+                    const HDR_Image img = light.emissive_copy();
+                    const auto [iw, ih] = img.dimension();
+                    std::vector<float> rgb(3 * iw * ih);
+                    for(size_t i = 0; i < iw * ih; i++) {
+                        const Spectrum px = img.at(i);
+                        rgb[3 * i] = px.r; rgb[3 * i + 1] = px.g; rgb[3 * i + 2] = px.b;
+                    }
+                    check(srt_pt_set_env_map(ctx, (uint32_t)iw, (uint32_t)ih, rgb.data()), "srt_pt_set_env_map");
                 } else {
                     check(srt_pt_set_env_light(ctx, SRT_ENV_SPHERE, rad), "srt_pt_set_env_light");
                 }

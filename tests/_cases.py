@@ -157,6 +157,18 @@ def pt_scene(name):
             {"type": 1, "radiance": np.array([0.2, 0.2, 0.2], np.float32), "T": np.eye(4, dtype=np.float32).reshape(16)},   # at the origin, no transform
         ]
         return s
+    if name == "cbox_envmap":
+        # the open Cornell box under an image environment map (Env_Map): a smooth sky gradient with a bright sun blob
+        # and some per-texel noise, 37 x 19 so that neither dimension is a power of two
+        s = pt_scene("cbox_envsphere")
+        rng = np.random.default_rng(5)
+        hh, ww = 19, 37
+        yy, xx = np.mgrid[0:hh, 0:ww].astype(np.float32)
+        img = np.stack([0.2 + 0.5 * yy / hh, 0.3 + 0.4 * xx / ww, 0.9 - 0.5 * yy / hh], -1).astype(np.float32)
+        img += (6.0 * np.exp(-((xx - 9) ** 2 + (yy - 4) ** 2) / 6.0))[..., None].astype(np.float32)
+        img += rng.random((hh, ww, 3), dtype=np.float32) * 0.1
+        s["env"] = {"type": 3, "image": np.ascontiguousarray(img, np.float32)}
+        return s
     if name in ("cbox_envsphere", "cbox_envhemi", "cbox_envonly"):
         # an open Cornell box (no ceiling, no back wall) under an environment light, so that rays escape:
         # uniform sphere + the area light (coin-flipped sampling, mean of the pdfs); hemisphere + the area light;
@@ -191,7 +203,8 @@ def scene_digest(scene):
         else:
             h.update(np.asarray([o["radius"]], np.float32).tobytes())
     if scene.get("env"):
-        h.update(np.asarray([scene["env"]["type"]], np.int32).tobytes() + np.asarray(scene["env"]["radiance"], np.float32).tobytes())
+        e = scene["env"]
+        h.update(np.asarray([e["type"]], np.int32).tobytes() + np.asarray(e["image"] if int(e["type"]) == 3 else e["radiance"], np.float32).tobytes())
     for l in scene.get("lights", []):
         h.update(np.asarray([l["type"]], np.int32).tobytes() + np.asarray(l["radiance"], np.float32).tobytes()
                  + np.asarray(l.get("angle_bounds", (0.0, 0.0)), np.float32).tobytes() + np.asarray(l["T"], np.float32).tobytes())

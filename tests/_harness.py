@@ -224,8 +224,11 @@ class _SceneFeeder:
                                int(o["material"]), bool(o["is_light"]))
             else:
                 self._add_sphere(float(o["radius"]), _f32(o["T"]), int(o["material"]))
-        if scene.get("env"):                  # environment light: {"type": 1 sphere | 2 hemisphere, "radiance"}
-            self._set_env(int(scene["env"]["type"]), _f32(scene["env"]["radiance"]))
+        if scene.get("env"):                  # {"type": 1 sphere | 2 hemisphere, "radiance"} or {"type": 3, "image": float32 [h, w, 3]}
+            if int(scene["env"]["type"]) == 3:
+                self._set_env_map(_f32(scene["env"]["image"]))
+            else:
+                self._set_env(int(scene["env"]["type"]), _f32(scene["env"]["radiance"]))
         for l in scene.get("lights", []):   # delta lights: {"type": 0 directional | 1 point | 2 spot, "radiance", "angle_bounds", "T"}
             self._add_light(int(l["type"]), _f32(l["radiance"]), _f32(l.get("angle_bounds", (0.0, 0.0))), _f32(l["T"]))
         self._commit()
@@ -257,6 +260,9 @@ class RefPT(_SceneFeeder):
 
     def _set_env(self, type_, radiance):
         assert self.lib.ref_pt_set_env_light(self.h_, type_, P(radiance)) == 0
+
+    def _set_env_map(self, image):
+        assert self.lib.ref_pt_set_env_map(self.h_, image.shape[1], image.shape[0], P(image)) == 0
 
     def _commit(self):
         assert self.lib.ref_pt_commit(self.h_) == 0
@@ -325,6 +331,9 @@ class OraclePT(_SceneFeeder):
 
     def _set_env(self, type_, radiance):
         assert self.lib.srt_oracle_pt_set_env_light(self.h_, type_, P(radiance)) == 0
+
+    def _set_env_map(self, image):
+        assert self.lib.srt_oracle_pt_set_env_map(self.h_, image.shape[1], image.shape[0], P(image)) == 0
 
     def _commit(self):
         rc = self.lib.srt_oracle_pt_commit(self.h_, int(self._use_bvh))
@@ -426,6 +435,9 @@ class EmuPT(_SceneFeeder):
         pass   # scene.hit only
 
     def _set_env(self, type_, radiance):
+        pass
+
+    def _set_env_map(self, image):
         pass
 
     def _commit(self):

@@ -55,6 +55,7 @@ int emu_commit(void* h, int use_bvh) {
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size(); S.tlas_nodes = F.tlas_nodes;
   S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.delta_lights = nullptr; S.ndelta = 0;
+  S.env_type = 0; S.env_map = nullptr; S.env_w = S.env_h = 0;
   S.w = S.h = 1; S.max_depth = 8;
   return 0;
 }

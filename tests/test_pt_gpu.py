@@ -143,6 +143,21 @@ def test_delta_lights(srt):
     pt.close()
 
 
+def test_environment_map(srt):
+    """Env_Map (image environment light) on the per-lane kernels against the oracle; the wave kernel refuses it."""
+    scene = pt_scene("cbox_envmap")
+    w, h, spp = 36, 28, 6
+    want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
+    pt = make_pt(srt, scene, w, h, 8, True)
+    for mode in (0, 1, 4):
+        pt.set_kernel(mode)
+        assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
+    pt.set_kernel(2)
+    with pytest.raises(srt.SrtError):
+        pt.render_epoch(8, 1, spp)
+    pt.close()
+
+
 @pytest.mark.parametrize("name", ["cbox_envsphere", "cbox_envhemi", "cbox_envonly"])
 def test_environment_lights(srt, name):
     """Env_Sphere / Env_Hemisphere: rays that leave the scene, sample_area_lights' coin flip, area_lights_pdf's mean -
