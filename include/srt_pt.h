@@ -73,6 +73,12 @@ int srt_pt_add_mesh(srt_pt* pt, const float* positions, const float* normals, ui
                     int is_area_light);
 /* Object(Shape(Sphere(radius)), id, material, T). */
 int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t material);
+/* An emissive analytic sphere (a Scene_Object with a Shape and a diffuse_light material): rays intersect the sphere
+ * (Sphere::hit), while the area-light list gets its triangle approximation obj.posed_mesh() as a Tri_Mesh without BVH
+ * (rays/pathtracer.cpp:105-116).  positions / normals / indices = that mesh. */
+int srt_pt_add_sphere_light(srt_pt* pt, float radius, const float trans[16], uint32_t material, const float* positions,
+                            const float* normals, uint32_t nverts, const uint32_t* indices, uint32_t nindices);
+
 /* A delta light (Pathtracer::point_lights, rays/pathtracer.cpp:26-64; rays/light.{h,cpp}): radiance =
  * Scene_Light::radiance(), trans = light.pose.transform() (column-major), angle_bounds (degrees) for spot lights
  * only.  Shadow rays of these lights are counted as rays like every other scene.hit. */

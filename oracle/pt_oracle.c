@@ -1121,6 +1121,27 @@ int srt_oracle_pt_add_mesh(void* h, const float* pos, const float* nrm, uint32_t
     mesh_fill(o, pos, nrm, nv, idx, ni);
     return 0;
 }
+/* An emissive Shape (rays/pathtracer.cpp:105-131): the analytic sphere in the scene, its mesh approximation in area_lights */
+int srt_oracle_pt_add_sphere_light(void* h, float radius, const float T[16], uint32_t material, const float* pos,
+                                   const float* nrm, uint32_t nv, const uint32_t* idx, uint32_t ni) {
+    scene_t* s = (scene_t*)h;
+    if (s->committed) return -1;
+    const uint32_t id = s->nobjs + 1;
+    s->lights = (object_t*)realloc(s->lights, (s->nlights + 1) * sizeof(object_t));
+    object_t* l = &s->lights[s->nlights++];
+    object_init(l, T, (int)material, id);
+    mesh_fill(l, pos, nrm, nv, idx, ni);
+    l->use_bvh = 0;
+    const m4 I = m_identity();
+    l->pdfT = I; l->pdfiT = I;
+    if (l->has_trans) { l->pdfT = m_mul(&I, &l->trans); l->pdfiT = m_mul(&l->itrans, &I); }
+    s->objs = (object_t*)realloc(s->objs, (s->nobjs + 1) * sizeof(object_t));
+    object_t* o = &s->objs[s->nobjs];
+    object_init(o, T, (int)material, s->nobjs + 1);
+    o->kind = OBJ_SPHERE; o->radius = radius;
+    s->nobjs++;
+    return 0;
+}
 /* Pathtracer::build_lights (rays/pathtracer.cpp:26-64): type 0 directional, 1 point, 2 spot */
 int srt_oracle_pt_add_light(void* h, uint32_t type, const float radiance[3], const float angle_bounds[2], const float T[16]) {
     scene_t* s = (scene_t*)h;

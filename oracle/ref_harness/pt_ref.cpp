@@ -167,6 +167,19 @@ int ref_pt_add_mesh(void* h, const float* pos, const float* nrm, uint32_t nv, co
   return 0;
 }
 
+// An emissive Shape as build_scene handles it (rays/pathtracer.cpp:105-131).
+int ref_pt_add_sphere_light(void* h, float radius, const float T[16], uint32_t material, const float* pos, const float* nrm,
+                            uint32_t nv, const uint32_t* idx, uint32_t ni) {
+  RefPT* r = (RefPT*)h;
+  Mat4 M = mat_from(T);
+  uint32_t id = (uint32_t)r->objs.size() + 1;
+  GL::Mesh lm = make_mesh(pos, nrm, nv, idx, ni);
+  r->lights.push_back(PT::Object(PT::Tri_Mesh(lm, false), id, material, M));
+  PT::Shape shape{PT::Sphere(radius)};
+  r->objs.emplace_back(std::move(shape), id, material, M);
+  return 0;
+}
+
 int ref_pt_add_sphere(void* h, float radius, const float T[16], uint32_t material) {
   RefPT* r = (RefPT*)h;
   uint32_t id = (uint32_t)r->objs.size() + 1;

@@ -26,6 +26,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_add_mesh.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_int]
     lib.srt_pt_set_env_light.argtypes = [c_void_p, c_uint32, c_void_p]
     lib.srt_pt_set_env_map.argtypes = [c_void_p, c_uint32, c_uint32, c_void_p]
+    lib.srt_pt_add_sphere_light.argtypes = [c_void_p, c_float, c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32]
     lib.srt_pt_add_light.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_add_sphere.argtypes = [c_void_p, c_float, c_void_p, c_uint32]
     lib.srt_pt_scene_commit.argtypes = [c_void_p, c_int]
@@ -133,6 +134,11 @@ class Pathtracer:
                 idx = np.ascontiguousarray(o["idx"], np.uint32)
                 self._check(L, L.srt_pt_add_mesh(self._ctx, _p(pos), _p(nrm), len(pos), _p(idx), len(idx), _p(T),
                                                  int(o["material"]), int(bool(o["is_light"]))))
+            elif o.get("light_mesh") is not None:   # emissive sphere
+                lm = o["light_mesh"]
+                pos, nrm, idx = _f32(lm["pos"]), _f32(lm["nrm"]), np.ascontiguousarray(lm["idx"], np.uint32)
+                self._check(L, L.srt_pt_add_sphere_light(self._ctx, float(o["radius"]), _p(T), int(o["material"]), _p(pos), _p(nrm),
+                                                         len(pos), _p(idx), len(idx)))
             else:
                 self._check(L, L.srt_pt_add_sphere(self._ctx, float(o["radius"]), _p(T), int(o["material"])))
         if d.get("env"):               # {"type": 1 sphere | 2 hemisphere, "radiance"} or {"type": 3, "image": float32 [h, w, 3]}

@@ -559,6 +559,25 @@ int srt_pt_add_sphere(srt_pt* pt, float radius, const float trans[16], uint32_t 
   return SRT_OK;
 }
 
+int srt_pt_add_sphere_light(srt_pt* pt, float radius, const float trans[16], uint32_t material, const float* positions,
+                            const float* normals, uint32_t nverts, const uint32_t* indices, uint32_t nindices) {
+  if (!pt || !trans || !positions || !normals || !indices) return srt::fail(SRT_ERR_INVALID, "srt_pt_add_sphere_light: NULL argument");
+  if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");
+  if (material >= pt->materials.size()) return srt::fail(SRT_ERR_INVALID, "material %u not defined", material);
+  if (!nverts || !nindices || nindices % 3) return srt::fail(SRT_ERR_INVALID, "the light mesh needs triangles (%u vertices, %u indices)", nverts, nindices);
+  ObjectInput o;
+  o.kind = OBJ_SPHERE;
+  std::memcpy(&o.trans, trans, sizeof(Mat4));
+  o.material = material;
+  o.radius = radius;
+  o.is_light = true;
+  o.mesh.pos.assign(positions, positions + 3 * (size_t)nverts);
+  o.mesh.nrm.assign(normals, normals + 3 * (size_t)nverts);
+  o.mesh.idx.assign(indices, indices + nindices);
+  pt->inputs.push_back(std::move(o));
+  return SRT_OK;
+}
+
 int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const float angle_bounds[2], const float trans[16]) {
   if (!pt || !radiance || !trans) return srt::fail(SRT_ERR_INVALID, "srt_pt_add_light: NULL argument");
   if (pt->committed) return srt::fail(SRT_ERR_STATE, "scene already committed; call srt_pt_scene_begin first");

@@ -258,7 +258,7 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
   for (uint32_t i = 0; i < nobj; i++) {
     const ObjectInput& in = objects[i];
     if (in.material >= materials.size()) return "object " + std::to_string(i) + " references an unknown material";
-    if (in.kind == OBJ_MESH) {
+    if (in.kind == OBJ_MESH || (in.is_light && !in.mesh.idx.empty())) {   // a mesh, or an emissive shape's light mesh
       if (in.mesh.idx.empty() || in.mesh.idx.size() % 3) return "mesh " + std::to_string(i) + " has no triangles";
       for (uint32_t v : in.mesh.idx)
         if ((size_t)v * 3 + 2 >= in.mesh.pos.size()) return "mesh " + std::to_string(i) + " has an out-of-range vertex index";
@@ -413,7 +413,9 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
   F.light_tri_first = (uint32_t)F.tris.size();
   for (uint32_t i = 0; i < nobj; i++) {
     const ObjectInput& in = objects[i];
-    if (!in.is_light || in.kind != OBJ_MESH) continue;
+    // an emissive analytic shape is intersected as the shape but lit through its triangle approximation
+    // (obj.posed_mesh(), rays/pathtracer.cpp:105-116): its ObjectInput carries that mesh next to the radius
+    if (!in.is_light || in.mesh.idx.empty()) continue;
     Light L;
     std::memset(&L, 0, sizeof L);
     L.has_trans = has_trans[i] ? 1u : 0u;

@@ -93,14 +93,23 @@ void Pathtracer::build_scene(Scene& layout_scene) {
                       "srt_pt_add_mesh");
             };
             if(obj.is_shape()) {
+                const float radius = obj.opt.shape.get<PT::Sphere>().radius;
                 if(is_light) {
-                    // The reference lights a shape through its triangle approximation (area_lights) but
-                    // intersects the analytic shape; the HIP path supports mesh lights only.
-                    if(!warned) warn("HIP path tracer: emissive analytic shapes are not supported; object skipped");
-                    warned = true;
-                    return;
+                    // The reference lights a shape through its triangle approximation (area_lights gets
+                    // Tri_Mesh(obj.posed_mesh(), false)) but intersects the analytic shape.
+                    const GL::Mesh& mesh = obj.posed_mesh();
+                    std::vector<float> pos, nrm;
+                    for(const auto& v : mesh.verts()) {
+                        pos.insert(pos.end(), {v.pos.x, v.pos.y, v.pos.z});
+                        nrm.insert(nrm.end(), {v.norm.x, v.norm.y, v.norm.z});
+                    }
+                    const auto& idxs = mesh.indices();
+                    check(srt_pt_add_sphere_light(ctx, radius, T, idx, pos.data(), nrm.data(), (uint32_t)mesh.verts().size(),
+                                                  idxs.data(), (uint32_t)idxs.size()),
+                          "srt_pt_add_sphere_light");
+                } else {
+                    check(srt_pt_add_sphere(ctx, radius, T, idx), "srt_pt_add_sphere");
                 }
-                check(srt_pt_add_sphere(ctx, obj.opt.shape.get<PT::Sphere>().radius, T, idx), "srt_pt_add_sphere");
             } else {
                 add_mesh(obj.posed_mesh(), is_light);
             }

@@ -157,6 +157,25 @@ def pt_scene(name):
             {"type": 1, "radiance": np.array([0.2, 0.2, 0.2], np.float32), "T": np.eye(4, dtype=np.float32).reshape(16)},   # at the origin, no transform
         ]
         return s
+    if name == "cbox_spherelight":
+        # an emissive analytic sphere next to the quad light: the sphere is intersected analytically, its triangle
+        # approximation (an octahedron subdivided twice, 128 triangles, scaled to the radius) is what the area-light
+        # sampler and pdf see (rays/pathtracer.cpp:105-131)
+        s = scenes.cornell_box("cbox")
+        radius = 0.12
+        v, f = scenes.blob_mesh(2, seed=1, radius=1.0)
+        v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+        flat_pos = (v[f.reshape(-1)] * np.float32(radius)).astype(np.float32)          # unindexed, flat-shaded like GL meshes
+        tri_n = np.cross(flat_pos[1::3] - flat_pos[0::3], flat_pos[2::3] - flat_pos[0::3])
+        tri_n /= np.linalg.norm(tri_n, axis=1, keepdims=True)
+        flat_nrm = np.repeat(tri_n, 3, axis=0).astype(np.float32)
+        idx = np.arange(len(flat_pos), dtype=np.uint32)
+        s["materials"].append({"type": scenes.DIFFUSE_LIGHT, "a": np.array([4.0, 3.0, 2.0], np.float32), "b": np.zeros(3, np.float32), "ior": 1.0})
+        Tm = np.eye(4, dtype=np.float32)
+        Tm[:3, 3] = (-0.3, 0.45, 0.25)
+        s["objects"].append({"kind": "sphere", "radius": radius, "T": np.ascontiguousarray(Tm.T.reshape(16)), "material": len(s["materials"]) - 1,
+                             "is_light": True, "light_mesh": {"pos": flat_pos, "nrm": flat_nrm, "idx": idx}})
+        return s
     if name == "cbox_envmap":
         # the open Cornell box under an image environment map (Env_Map): a smooth sky gradient with a bright sun blob
         # and some per-texel noise, 37 x 19 so that neither dimension is a power of two
@@ -202,6 +221,9 @@ def scene_digest(scene):
                      + np.asarray(o["idx"], np.uint32).tobytes() + bytes([int(o["is_light"])]))
         else:
             h.update(np.asarray([o["radius"]], np.float32).tobytes())
+            if o.get("light_mesh") is not None:
+                lm = o["light_mesh"]
+                h.update(np.asarray(lm["pos"], np.float32).tobytes() + np.asarray(lm["nrm"], np.float32).tobytes() + np.asarray(lm["idx"], np.uint32).tobytes())
     if scene.get("env"):
         e = scene["env"]
         h.update(np.asarray([e["type"]], np.int32).tobytes() + np.asarray(e["image"] if int(e["type"]) == 3 else e["radiance"], np.float32).tobytes())

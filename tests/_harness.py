@@ -222,6 +222,10 @@ class _SceneFeeder:
             if o["kind"] == "mesh":
                 self._add_mesh(_f32(o["pos"]), _f32(o["nrm"]), np.ascontiguousarray(o["idx"], np.uint32), _f32(o["T"]),
                                int(o["material"]), bool(o["is_light"]))
+            elif o.get("light_mesh") is not None:     # emissive sphere: analytic shape + its triangle approximation as the light
+                lm = o["light_mesh"]
+                self._add_sphere_light(float(o["radius"]), _f32(o["T"]), int(o["material"]), _f32(lm["pos"]), _f32(lm["nrm"]),
+                                       np.ascontiguousarray(lm["idx"], np.uint32))
             else:
                 self._add_sphere(float(o["radius"]), _f32(o["T"]), int(o["material"]))
         if scene.get("env"):                  # {"type": 1 sphere | 2 hemisphere, "radiance"} or {"type": 3, "image": float32 [h, w, 3]}
@@ -254,6 +258,9 @@ class RefPT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.ref_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_sphere_light(self, radius, T, material, pos, nrm, idx):
+        assert self.lib.ref_pt_add_sphere_light(self.h_, ctypes.c_float(radius), P(T), material, P(pos), P(nrm), len(pos), P(idx), len(idx)) == 0
 
     def _add_light(self, type_, radiance, angle_bounds, T):
         assert self.lib.ref_pt_add_light(self.h_, type_, P(radiance), P(angle_bounds), P(T)) == 0
@@ -325,6 +332,9 @@ class OraclePT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.srt_oracle_pt_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_sphere_light(self, radius, T, material, pos, nrm, idx):
+        assert self.lib.srt_oracle_pt_add_sphere_light(self.h_, ctypes.c_float(radius), P(T), material, P(pos), P(nrm), len(pos), P(idx), len(idx)) == 0
 
     def _add_light(self, type_, radiance, angle_bounds, T):
         assert self.lib.srt_oracle_pt_add_light(self.h_, type_, P(radiance), P(angle_bounds), P(T)) == 0
@@ -430,6 +440,9 @@ class EmuPT(_SceneFeeder):
 
     def _add_sphere(self, radius, T, material):
         assert self.lib.emu_add_sphere(self.h_, ctypes.c_float(radius), P(T), material) == 0
+
+    def _add_sphere_light(self, radius, T, material, pos, nrm, idx):
+        self._add_sphere(radius, T, material)
 
     def _add_light(self, type_, radiance, angle_bounds, T):
         pass   # scene.hit only

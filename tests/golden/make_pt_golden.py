@@ -41,6 +41,7 @@ CASES = [
     ("cbox_envhemi", 32, 24, 5, True, 1024, None),              # Env_Hemisphere: radiance only for dir.y > 0
     ("cbox_envonly", 32, 24, 8, False, 1024, (16, 12, 4)),      # environment light alone (no area lights)
     ("cbox_envmap", 40, 32, 8, True, 2048, (20, 16, 6)),        # Env_Map: bilinear image lookup (acos / atan2), uniform sampling
+    ("cbox_spherelight", 40, 32, 8, True, 2048, (20, 16, 6)),   # emissive analytic sphere lit through its triangle approximation
 ]
 SEED = 20260331
 

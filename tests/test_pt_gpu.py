@@ -143,6 +143,18 @@ def test_delta_lights(srt):
     pt.close()
 
 
+def test_emissive_sphere(srt):
+    """An emissive analytic sphere (intersected as a sphere, sampled through its mesh approximation) on every kernel."""
+    scene = pt_scene("cbox_spherelight")
+    w, h, spp = 36, 28, 6
+    want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
+    pt = make_pt(srt, scene, w, h, 8, True)
+    for mode in (0, 1, 2, 4, 5):
+        pt.set_kernel(mode)
+        assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
+    pt.close()
+
+
 def test_environment_map(srt):
     """Env_Map (image environment light) on the per-lane kernels against the oracle; the wave kernel refuses it."""
     scene = pt_scene("cbox_envmap")
