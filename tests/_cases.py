@@ -157,6 +157,30 @@ def pt_scene(name):
             {"type": 1, "radiance": np.array([0.2, 0.2, 0.2], np.float32), "T": np.eye(4, dtype=np.float32).reshape(16)},   # at the origin, no transform
         ]
         return s
+    if name == "cbox_particles":
+        # what Scene_Particles turns into: the Cornell box plus 60 small posed copies of one 32-triangle mesh and a few
+        # extra spheres - a BVH<Object> of 74 objects, more than the wave-uniform kernels take
+        s = scenes.cornell_box("cbox_lambertian")
+        rng = np.random.default_rng(21)
+        v, f = scenes.blob_mesh(1, seed=3, radius=1.0)
+        flat_pos = v[f.reshape(-1)].astype(np.float32)
+        tri_n = np.cross(flat_pos[1::3] - flat_pos[0::3], flat_pos[2::3] - flat_pos[0::3])
+        tri_n /= np.linalg.norm(tri_n, axis=1, keepdims=True)
+        flat_nrm = np.repeat(tri_n, 3, axis=0).astype(np.float32)
+        idx = np.arange(len(flat_pos), dtype=np.uint32)
+        s["materials"].append({"type": scenes.LAMBERTIAN, "a": np.array([0.2, 0.6, 0.3], np.float32), "b": np.zeros(3, np.float32), "ior": 1.0})
+        mat = len(s["materials"]) - 1
+        for k in range(60):
+            Tm = np.eye(4, dtype=np.float32)
+            Tm[0, 0] = Tm[1, 1] = Tm[2, 2] = np.float32(0.03)                      # Mat4::translate(p.pos) * Mat4::scale(scale)
+            Tm[:3, 3] = (rng.random(3) * [1.2, 0.8, 1.2] - [0.6, -0.1, 0.6]).astype(np.float32)
+            s["objects"].append({"kind": "mesh", "pos": flat_pos, "nrm": flat_nrm, "idx": idx, "T": np.ascontiguousarray(Tm.T.reshape(16)),
+                                 "material": mat, "is_light": False})
+        for k in range(6):
+            Tm = np.eye(4, dtype=np.float32)
+            Tm[:3, 3] = (rng.random(3) * [1.0, 0.6, 1.0] - [0.5, -0.2, 0.5]).astype(np.float32)
+            s["objects"].append({"kind": "sphere", "radius": 0.04, "T": np.ascontiguousarray(Tm.T.reshape(16)), "material": mat, "is_light": False})
+        return s
     if name == "cbox_spherelight":
         # an emissive analytic sphere next to the quad light: the sphere is intersected analytically, its triangle
         # approximation (an octahedron subdivided twice, 128 triangles, scaled to the radius) is what the area-light

@@ -143,6 +143,28 @@ def test_delta_lights(srt):
     pt.close()
 
 
+def test_many_objects(srt):
+    """A BVH<Object> of 74 objects (what a particle system becomes): per-lane kernels against the oracle, BVH and list;
+    the wave-uniform builds refuse it."""
+    scene = pt_scene("cbox_particles")
+    w, h, spp = 40, 32, 3
+    pt = make_pt(srt, scene, w, h, 6, True)
+    want = H.OraclePT(scene, w, h, 6, True).epoch(4, 0, spp)
+    for mode in (0, 1, 4):
+        pt.set_kernel(mode)
+        assert bits_equal(pt.render_epoch(4, 0, spp), want), f"kernel mode {mode}"
+    org, d, b = random_rays(5, 3000)
+    assert bits_equal(pt.hit(org, d, b), H.OraclePT(scene, w, h, 6, True).hit(org, d, b))
+    for mode in (2, 5):
+        pt.set_kernel(mode)
+        with pytest.raises(srt.SrtError):
+            pt.render_epoch(4, 0, spp)
+    pt.close()
+    pt = make_pt(srt, scene, w, h, 6, False)
+    assert bits_equal(pt.render_epoch(4, 0, 2), H.OraclePT(scene, w, h, 6, False).epoch(4, 0, 2))
+    pt.close()
+
+
 def test_emissive_sphere(srt):
     """An emissive analytic sphere (intersected as a sphere, sampled through its mesh approximation) on every kernel."""
     scene = pt_scene("cbox_spherelight")
