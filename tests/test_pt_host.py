@@ -95,3 +95,35 @@ def test_scene_argument_checks(srt):
     with pytest.raises(srt.SrtError):
         pt.set_params(4, 4, 1, 99, True)   # deeper than the per-bounce record stack
     pt.close()
+
+
+def test_light_and_environment_argument_checks(srt):
+    """Error behaviour of the scene-assembly calls added for lights (host-only context: no device needed)."""
+    import ctypes
+
+    pt = srt.Pathtracer(device=-1)
+    L, ctx = pt._lib, pt._ctx
+    assert L.srt_pt_scene_begin(ctx) == 0
+    rad = np.array([1, 1, 1], np.float32)
+    ab = np.array([30, 60], np.float32)
+    T = np.eye(4, dtype=np.float32).reshape(16)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert L.srt_pt_add_light(ctx, 3, P(rad), P(ab), P(T)) == -1                    # SRT_ERR_INVALID: unknown type
+    assert L.srt_pt_add_light(ctx, 2, P(rad), None, P(T)) == -1                     # a spot light needs its cone
+    assert L.srt_pt_add_light(ctx, 1, None, None, P(T)) == -1
+    assert L.srt_pt_add_light(ctx, 1, P(rad), None, P(T)) == 0
+    assert L.srt_pt_set_env_light(ctx, 4, P(rad)) == -1
+    assert L.srt_pt_set_env_light(ctx, 1, None) == -1
+    assert L.srt_pt_set_env_light(ctx, 2, P(rad)) == 0
+    assert L.srt_pt_set_env_light(ctx, 0, None) == 0                                # back to "none"
+    img = np.zeros((2, 3, 3), np.float32)
+    assert L.srt_pt_set_env_map(ctx, 0, 2, P(img)) == -1
+    assert L.srt_pt_set_env_map(ctx, 3, 2, None) == -1
+    assert L.srt_pt_set_env_map(ctx, 3, 2, P(img)) == 0
+    pos = np.zeros((3, 3), np.float32); idx = np.arange(3, dtype=np.uint32)
+    assert L.srt_pt_add_sphere_light(ctx, ctypes.c_float(0.1), P(T), 0, P(pos), P(pos), 3, P(idx), 3) == -1   # no material yet
+    assert b"material" in L.srt_last_error()
+    pt.build_scene(pt_scene("cbox"))                                                # commit a scene
+    assert L.srt_pt_add_light(ctx, 1, P(rad), None, P(T)) == -5                     # SRT_ERR_STATE: already committed
+    assert L.srt_pt_set_env_light(ctx, 1, P(rad)) == -5
+    pt.close()
