@@ -21,6 +21,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "pt_device.h"
@@ -220,10 +221,15 @@ struct srt_pt {
   float* d_tile_buf = nullptr; size_t tile_buf_floats = 0;
   float* d_image = nullptr; size_t image_floats = 0;
   int kernel_mode = 0;        // 0 auto, 1 general per-lane kernel, 2 wave-uniform persistent kernel
-  float* d_samples = nullptr; size_t samples_floats = 0;   // wave kernel: per-unit radiance
-  float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
-  float* d_running = nullptr; size_t running_floats = 0;   // wave kernel: (sum, count) across launches
-  unsigned long long* d_queue = nullptr;                   // wave kernel: queue head
+  // Scratch of one epoch in flight.  One set per stream the caller renders on: epochs launched on different streams
+  // may overlap on the device (the next epoch's blocks fill the CUs the previous launch's tail leaves idle).
+  struct EpochBuffers {
+    float* d_samples = nullptr; size_t samples_floats = 0;   // per-sample radiance
+    float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
+    float* d_running = nullptr; size_t running_floats = 0;   // (sum, count) across the launches of one epoch
+    unsigned long long* d_queue = nullptr;                   // wave kernel: queue head (+ section stamps)
+  };
+  std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
   unsigned long long last_counters[C_COUNT] = {0};
@@ -382,12 +388,13 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const uint32_t chunk = samples_per_launch(px);
   const uint32_t nlanes = (uint32_t)pt->wave_blocks * 256;
   int st;
-  if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
-  if ((st = ensure(&pt->d_records, &pt->records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
-  if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
-  if (!pt->d_queue) {
-    SRT_HIP(hipMalloc(&pt->d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
-    SRT_HIP(hipMemset(pt->d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
+  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
+  if ((st = ensure(&B.d_records, &B.records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
+  if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
+  if (!B.d_queue) {
+    SRT_HIP(hipMalloc(&B.d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
+    SRT_HIP(hipMemset(B.d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
   }
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
@@ -404,16 +411,16 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.groups3 = (n - P.singles) / kBurst;
     P.units3 = px * P.groups3;
     P.total_units = px * (P.groups3 + P.singles); P.nlanes = nlanes;
-    P.sample_out = pt->d_samples; P.records = pt->d_records;
+    P.sample_out = B.d_samples; P.records = B.d_records;
     // one unit per lane per queue atomic: with the 512-unit grabs of the first version the last grabs decided the
     // launch time (a 1/8 image shard ran at 56 % of the full-image rate; 83 % with 64, and the full image gained 6 %)
     P.npix = px;
     P.chunk = getenv("SRT_WAVE_CHUNK") ? (uint32_t)atoi(getenv("SRT_WAVE_CHUNK")) : kChunk;
     P.flat_ready = getenv("SRT_FLAT_READY") ? (uint32_t)atoi(getenv("SRT_FLAT_READY")) : kFlatReady;
     P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;
-    P.queue_head = pt->d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = pt->d_queue + 1;
+    P.queue_head = B.d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = B.d_queue + 1;
     if (n) {
-      SRT_HIP(hipMemsetAsync(pt->d_queue, 0, sizeof(unsigned long long), s));
+      SRT_HIP(hipMemsetAsync(B.d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
 #define SRT_LAUNCH_WAVE(STAMP_, TRAV_, DL_)                                                                                   \
   pt_wave_kernel<STAMP_, TRAV_, DL_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm,       \
@@ -429,7 +436,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
-    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, pt->d_samples, pt->d_running, first, last, d_tiles_out);
+    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
     SRT_HIP(hipGetLastError());
     if (samples == 0) break;
   }
@@ -442,20 +449,21 @@ int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const uint32_t chunk = samples_per_launch(px);
   int st;
-  if ((st = ensure(&pt->d_samples, &pt->samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
-  if ((st = ensure(&pt->d_running, &pt->running_floats, (size_t)px * 4)) != SRT_OK) return st;
+  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
+  if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     const uint64_t units = (uint64_t)px * n;
     if (n) {
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
       pt_unit_kernel<<<dim3((unsigned)((units + 63) / 64)), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base + done, n,
-                                                                              (uint32_t)units, pt->d_samples, pt->d_totals + C_COUNT);
+                                                                              (uint32_t)units, B.d_samples, pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
-    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, pt->d_samples, pt->d_running, first, last, d_tiles_out);
+    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
     SRT_HIP(hipGetLastError());
     if (samples == 0) break;
   }
@@ -500,7 +508,9 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
-    (void)hipFree(pt->d_samples); (void)hipFree(pt->d_records); (void)hipFree(pt->d_running); (void)hipFree(pt->d_queue);
+    for (auto& kv : pt->epoch_buffers) {
+      (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
+    }
     for (auto& v : {&pt->timed, &pt->spare})
       for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(pt->stream);
@@ -783,12 +793,14 @@ int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset) {
   if (st != SRT_OK) return st;
   if (!out) return srt::fail(SRT_ERR_INVALID, "srt_pt_section_cycles: NULL argument");
   for (int i = 0; i < 8; i++) out[i] = 0;
-  if (!pt->d_queue) return SRT_OK;
   SRT_HIP(hipDeviceSynchronize());
-  unsigned long long h[ST_COUNT_];
-  SRT_HIP(hipMemcpy(h, pt->d_queue + 1, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < ST_COUNT_; i++) out[i] = h[i];
-  if (reset) SRT_HIP(hipMemset(pt->d_queue + 1, 0, sizeof h));
+  for (auto& kv : pt->epoch_buffers) {   // summed over the streams that rendered
+    if (!kv.second.d_queue) continue;
+    unsigned long long h[ST_COUNT_];
+    SRT_HIP(hipMemcpy(h, kv.second.d_queue + 1, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ST_COUNT_; i++) out[i] += h[i];
+    if (reset) SRT_HIP(hipMemset(kv.second.d_queue + 1, 0, sizeof h));
+  }
   return SRT_OK;
 }
 

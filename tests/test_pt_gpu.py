@@ -394,3 +394,31 @@ def test_large_image_multi_launch(srt):
         want = (acc * np.float32(1.0 / n)).astype(np.float32) if n else acc
         assert bits_equal(img[y, x], want), (x, y)
     pt.close()
+
+
+def test_epochs_on_two_streams_overlap_safely(srt):
+    """Epochs launched alternately on two streams (each stream has its own epoch scratch in the library, so consecutive
+    launches may overlap on the device) give the same tiles as the same epochs on one stream."""
+    import torch
+
+    scene = pt_scene("cbox")
+    w, h, spp = 96, 64, 9
+    pt = make_pt(srt, scene, w, h, 8, True)
+    pt.set_tiling(32, 32, 0, 1)
+    _, per_rank, fpt = pt.tile_info()
+    one = torch.cuda.current_stream()
+    want = []
+    for i in range(6):
+        t = torch.zeros(per_rank * fpt, dtype=torch.float32, device="cuda")
+        pt.render_epoch_device(one.cuda_stream, 3, i * spp, spp, t.data_ptr())
+        want.append(t)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [torch.zeros(per_rank * fpt, dtype=torch.float32, device="cuda") for _ in range(6)]
+    torch.cuda.synchronize()
+    for i in range(6):
+        pt.render_epoch_device(streams[i % 2].cuda_stream, 3, i * spp, spp, got[i].data_ptr())
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    pt.close()
