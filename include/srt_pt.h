@@ -177,6 +177,12 @@ int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, floa
 /* The kernels' acosf (glibc 2.35's algorithm restated; Samplers::Hemisphere::Uniform) evaluated on the device. */
 int srt_pt_math_acos(srt_pt* pt, const float* x, size_t n, float* out);
 
+/* The wave kernel's batched IEEE divide / square root (pt_device.h: div3x3, sqrt3) on host operands, called exactly as
+ * the batch tests call them: lane i handles operands 3i, 3i+1, 3i+2.  in: five planes of 3*lanes floats (num0, num1,
+ * num2, den, x); out: four planes (num0/den, num1/den, num2/den, sqrt(x)).  shared_c2 != 0: a lane's three rays share
+ * num2[3i].  Parity tests compare the planes with the host's correctly rounded `/` and sqrtf. */
+int srt_pt_math_div_sqrt(srt_pt* pt, const float* in, size_t lanes, int shared_c2, float* out);
+
 int srt_pt_sync(srt_pt* pt);
 
 #ifdef __cplusplus

@@ -50,6 +50,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_math_cos_sin.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
     lib.srt_pt_math_acos.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_math_atan2.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_math_div_sqrt.argtypes = [c_void_p, c_void_p, c_size_t, ctypes.c_int, c_void_p]
     lib.srt_pt_sync.argtypes = [c_void_p]
 
 
@@ -283,6 +284,15 @@ class Pathtracer:
         out = np.zeros(len(y), np.float32)
         self._check(self._lib, self._lib.srt_pt_math_atan2(self._ctx, _p(y), _p(x), len(y), _p(out)))
         return out
+
+    def math_div_sqrt(self, num0, num1, num2, den, x, shared_c2=False):
+        """(num0/den, num1/den, num2/den, sqrt(x)) through the wave kernel's div3x3 / sqrt3; len % 3 == 0."""
+        planes = np.ascontiguousarray(np.stack([_f32(num0), _f32(num1), _f32(num2), _f32(den), _f32(x)]))
+        n3 = planes.shape[1]
+        assert n3 % 3 == 0
+        out = np.zeros((4, n3), np.float32)
+        self._check(self._lib, self._lib.srt_pt_math_div_sqrt(self._ctx, _p(planes), n3 // 3, int(bool(shared_c2)), _p(out)))
+        return out[0], out[1], out[2], out[3]
 
     def math_cos_sin(self, x):
         x = _f32(x)

@@ -191,6 +191,34 @@ __global__ void pt_atan2_kernel(const float* __restrict__ y, const float* __rest
   if (i < n) out[i] = srt_atan2f(y[i], x[i]);
 }
 
+// Diagnostic for div3x3 / sqrt3 (pt_device.h): lane i takes the operands of "rays" 3i, 3i+1, 3i+2 — exactly how the
+// wave kernel's batch tests call them.  io layout: planes of n3 = 3 * lanes floats: num0, num1, num2, den, x in; q0, q1, q2,
+// root out.  shared_c2: column 2's numerator of a lane is num2[3i] for its three rays (the triangle test's shared t numerator).
+__global__ void pt_div_sqrt_kernel(const float* __restrict__ in, size_t lanes, int shared_c2, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n3 = lanes * 3;
+  const size_t k = (i < lanes ? i : lanes - 1) * 3;     // every lane of the last wave computes; the spares repeat the last lane
+  float num[3][3], den[3], q[3][3], x[3], root[3];
+  bool zero[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    num[r][0] = in[k + r]; num[r][1] = in[n3 + k + r];
+    num[r][2] = in[2 * n3 + (shared_c2 ? k : k + r)];
+    den[r] = in[3 * n3 + k + r];
+    x[r] = in[4 * n3 + k + r];
+    zero[r] = __float_as_uint(x[r]) == 0u;
+  }
+  if (shared_c2) div3x3<true>(num, den, q); else div3x3<false>(num, den, q);
+  sqrt3(x, zero, root);
+  if (i < lanes) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      out[k + r] = q[r][0]; out[n3 + k + r] = q[r][1]; out[2 * n3 + k + r] = q[r][2];
+      out[3 * n3 + k + r] = root[r];
+    }
+  }
+}
+
 }  // namespace srt
 
 // ---------------------------------------------------------------------------------------------------
@@ -968,6 +996,23 @@ int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, floa
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
+  return SRT_OK;
+}
+
+int srt_pt_math_div_sqrt(srt_pt* pt, const float* in, size_t lanes, int shared_c2, float* out) {
+  int st = need_device(pt, "srt_pt_math_div_sqrt");
+  if (st != SRT_OK) return st;
+  if (!in || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_div_sqrt: NULL argument");
+  if (!lanes) return SRT_OK;
+  const size_t n3 = lanes * 3;
+  float *din = nullptr, *dout = nullptr;
+  SRT_HIP(hipMalloc(&din, 5 * n3 * 4)); SRT_HIP(hipMalloc(&dout, 4 * n3 * 4));
+  SRT_HIP(hipMemcpyAsync(din, in, 5 * n3 * 4, hipMemcpyHostToDevice, pt->stream));
+  pt_div_sqrt_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, pt->stream>>>(din, lanes, shared_c2, dout);
+  SRT_HIP(hipGetLastError());
+  SRT_HIP(hipMemcpyAsync(out, dout, 4 * n3 * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  (void)hipFree(din); (void)hipFree(dout);
   return SRT_OK;
 }
 

@@ -26,6 +26,100 @@ struct V3 { float x, y, z; };
 struct Spec { float r, g, b; };
 struct Ray { V3 o, d; float b0, b1; };
 
+// ---- IEEE divide / square root with the range handling hoisted out of the common case ----
+// hipcc expands a correctly rounded fp32 divide to v_div_scale x2, v_rcp, a five-step FMA refinement, v_div_fmas and
+// v_div_fixup, and a square root to v_sqrt plus a +-1 ulp correction wrapped in denormal scaling and a class
+// fix-up.  When no operand needs scaling or fixing (every lane's operands are normal numbers well inside the
+// exponent range: v_div_scale returns its input, VCC = 0, v_div_fixup and the sqrt fix-ups pass the result
+// through) what remains is the refinement itself, and the part of it that only depends on the denominator can
+// be shared by the quotients of one triangle test (u, v, t over det) or one normalisation (x, y, z over the norm).
+// Used by the wave kernel's batch tests only (three rays at a time, so the serial refinement chains overlap).
+// The fast path is taken when the whole wave qualifies; any other operand sends the wave through the compiler's
+// own sequence, so the results are those of the plain `/` and sqrtf for every input
+// (tests/test_pt_gpu.py::test_exact_division_and_sqrt_fast_paths sweeps both against them).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SRT_PLAIN_DIV_SQRT)
+#define SRT_EXACT_FAST_PATHS 1
+#else
+#define SRT_EXACT_FAST_PATHS 0
+#endif
+
+#if SRT_EXACT_FAST_PATHS
+SRT_DEV float div_refine(float num, float den, float r) {
+  float q = num * r;
+  const float e1 = __builtin_fmaf(-den, q, num);
+  q = __builtin_fmaf(e1, r, q);
+  const float e2 = __builtin_fmaf(-den, q, num);
+  return __builtin_fmaf(e2, r, q);
+}
+#endif
+// Three square roots / nine quotients (the three rays of a batch): one range verdict for all operands, and the
+// refinement chains of the three rays are independent instruction streams inside one basic block.
+// zero[r] = "x[r] is exactly +0" as the caller knows it (origin on the triangle's plane: t = 0; a ray without a hit:
+// distance of a point from itself): v_sqrt(0) = 0 and neither correction applies, so a zero may take the fast path.
+SRT_DEV void sqrt3(const float* x, const bool* zero, float* o) {
+#if SRT_EXACT_FAST_PATHS
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 3; r++) bad = bad || (!zero[r] && !(x[r] >= 0x1p-96f && x[r] <= FLT_MAX));
+  if (__ballot(bad) == 0ull) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float s = __builtin_amdgcn_sqrtf(x[r]);
+      const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+      const float rm = __builtin_fmaf(-sm, s, x[r]), rp = __builtin_fmaf(-sp, s, x[r]);
+      float v = (0.0f >= rm) ? sm : s;
+      v = (0.0f < rp) ? sp : v;
+      o[r] = v;
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = sqrtf(x[r]);
+}
+// q[r][j] = n[r][j] / den[r].  SHARED_C2: the caller passes the same numerator in column 2 for the three rays (the
+// numerator of t), which is exactly zero for an origin on the triangle's plane; such a lane takes the fast path as
+// well and v_div_fixup gives the signed zero the full sequence would.
+template <bool SHARED_C2>
+SRT_DEV void div3x3(const float (*n)[3], const float* den, float (*q)[3]) {
+#if SRT_EXACT_FAST_PATHS
+  const float lo = 0x1p-40f, hi = 0x1p40f;     // quotient exponents stay within +-80: no scaling case of v_div_scale
+  float mn = fminf(fminf(fabsf(den[0]), fabsf(den[1])), fabsf(den[2]));
+  float mx = fmaxf(fmaxf(fabsf(den[0]), fabsf(den[1])), fabsf(den[2]));
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    if (SHARED_C2) {
+      mn = fminf(mn, fminf(fabsf(n[r][0]), fabsf(n[r][1])));
+      mx = fmaxf(mx, fmaxf(fabsf(n[r][0]), fabsf(n[r][1])));
+    } else {
+      mn = fminf(fminf(mn, fabsf(n[r][0])), fminf(fabsf(n[r][1]), fabsf(n[r][2])));
+      mx = fmaxf(fmaxf(mx, fabsf(n[r][0])), fmaxf(fabsf(n[r][1]), fabsf(n[r][2])));
+    }
+  }
+  if (SHARED_C2) {
+    const float c2 = (n[0][2] == 0.0f) ? 1.0f : fabsf(n[0][2]);
+    mn = fminf(mn, c2); mx = fmaxf(mx, c2);
+  }
+  // (min / max skip a NaN operand: it stays a NaN through the refinement, as it would through the full sequence)
+  if (__ballot(!(mn >= lo && mx <= hi)) == 0ull) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      float rc = __builtin_amdgcn_rcpf(den[r]);
+      const float e = __builtin_fmaf(-den[r], rc, 1.0f);
+      rc = __builtin_fmaf(e, rc, rc);
+#pragma unroll
+      for (int j = 0; j < 3; j++) q[r][j] = div_refine(n[r][j], den[r], rc);
+      if (SHARED_C2) q[r][2] = __builtin_amdgcn_div_fixupf(q[r][2], den[r], n[r][2]);
+    }
+    return;
+  }
+#endif
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) q[r][j] = n[r][j] / den[r];
+}
+
 SRT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 SRT_DEV V3 v3p(const float* p) { return v3(p[0], p[1], p[2]); }
 SRT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -37,7 +131,7 @@ SRT_DEV float dot(V3 l, V3 r) { return l.x * r.x + l.y * r.y + l.z * r.z; }
 SRT_DEV V3 cross(V3 l, V3 r) { return v3(l.y * r.z - l.z * r.y, l.z * r.x - l.x * r.z, l.x * r.y - l.y * r.x); }
 SRT_DEV float norm2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 SRT_DEV float norm(V3 a) { return sqrtf(norm2(a)); }
-SRT_DEV V3 unit(V3 a) { const float n = norm(a); return v3(a.x / n, a.y / n, a.z / n); }
+SRT_DEV V3 unit(V3 a) { return a / norm(a); }
 SRT_DEV float std_min(float a, float b) { return (b < a) ? b : a; }
 SRT_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
 
@@ -321,6 +415,38 @@ SRT_DEV TriHit tri_hit(const Tri& g, const Ray& ray) {
   const bool out_of_bounds = (h.dist < ray.b0) || (h.dist > ray.b1);
   h.hit = (det != 0) && !outside && !out_of_bounds;
   return h;
+}
+
+// Triangle::hit of one triangle for the three rays of a batch (shared origin): s, s x e2 and the numerator of t do
+// not depend on the direction; the nine quotients and the three distances go through div3x3 / sqrt3.
+SRT_DEV void tri_hit3(const Tri& g, V3 org, const V3* d, const float* b0, const float* b1, TriHit* h) {
+  const V3 e1 = v3p(g.e1), e2 = v3p(g.e2);
+  const V3 s = org - v3p(g.p0);
+  const V3 sxe2 = cross(s, e2);
+  const float nt = -1.0f * dot(sxe2, e1);
+  float num[3][3], det[3], q[3][3], n2[3], nr[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const V3 e1xd = cross(e1, d[r]);
+    det[r] = dot(e1xd, e2);
+    num[r][0] = -1.0f * dot(sxe2, d[r]);
+    num[r][1] = dot(e1xd, s);
+    num[r][2] = nt;
+  }
+  div3x3<true>(num, det, q);
+#pragma unroll
+  for (int r = 0; r < 3; r++) n2[r] = norm2(d[r] * q[r][2]);
+  const bool on_plane = nt == 0.0f;             // t = +-0 for the three rays: the distances are exactly +0
+  const bool zero[3] = {on_plane, on_plane, on_plane};
+  sqrt3(n2, zero, nr);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    h[r].u = q[r][0]; h[r].v = q[r][1]; h[r].t = q[r][2];
+    const bool outside = (h[r].u < 0) || (h[r].v < 0) || ((1.0f - h[r].u - h[r].v) < 0) || (h[r].t < 0);
+    h[r].dist = fabsf(nr[r]);
+    const bool out_of_bounds = (h[r].dist < b0[r]) || (h[r].dist > b1[r]);
+    h[r].hit = (det[r] != 0) && !outside && !out_of_bounds;
+  }
 }
 
 // Sphere::hit (student/shapes.cpp:17-80).  The reference's unqualified sqrt(delta) is the double overload,

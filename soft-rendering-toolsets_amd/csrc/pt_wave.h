@@ -157,51 +157,87 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
   const Object& o = S.objects[k];
   const bool xf = o.has_trans != 0;
   V3 oorg = org;
-  if (xf) oorg = mat_point_uniform(o.itrans, org);
-  V3 pos[3];
+  V3 od[3] = {d[0], d[1], d[2]};
+  float ob0[3] = {rb0[0], rb0[1], rb0[2]}, ob1[3] = {rb1[0], rb1[1], rb1[2]};
+  if (xf) {                                           // Ray::transform with the shared origin
+    oorg = mat_point_uniform(o.itrans, org);
+    float n2[3], dn[3], num[3][3], q[3][3];
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    Ray ray;
-    ray.o = oorg; ray.d = d[r]; ray.b0 = rb0[r]; ray.b1 = rb1[r];
-    if (xf) {                                         // Ray::transform with the shared origin
-      ray.d = mat_rotate(o.itrans, d[r]);
-      const float dn = norm(ray.d);
-      ray.b0 *= dn; ray.b1 *= dn;
-      ray.d = ray.d / dn;
+    for (int r = 0; r < 3; r++) {
+      const V3 rd = mat_rotate(o.itrans, d[r]);
+      num[r][0] = rd.x; num[r][1] = rd.y; num[r][2] = rd.z;
+      n2[r] = norm2(rd);
     }
-    tri[r] = 0;
-    if (o.kind == OBJ_SPHERE) {
+    const bool nz[3] = {false, false, false};
+    sqrt3(n2, nz, dn);
+    div3x3<false>(num, dn, q);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      ob0[r] *= dn[r]; ob1[r] *= dn[r];
+      od[r] = v3(q[r][0], q[r][1], q[r][2]);
+    }
+  }
+  V3 pos[3];
+  if (o.kind == OBJ_SPHERE) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      Ray ray;
+      ray.o = oorg; ray.d = od[r]; ray.b0 = ob0[r]; ray.b1 = ob1[r];
       const SphHit sh = sphere_hit(o.radius, ray);
-      hit[r] = sh.hit;
+      hit[r] = sh.hit; tri[r] = 0;
       pos[r] = ray_at(ray, sh.t);
-      dist[r] = fabsf(norm(pos[r] - ray.o));
-    } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) { // a real BVH<Triangle>: per-lane walk
+    }
+    float n2[3], nr[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) n2[r] = norm2(pos[r] - oorg);
+    const bool miss[3] = {!hit[0], !hit[1], !hit[2]};   // no hit: t = 0, pos == origin
+    sqrt3(n2, miss, nr);
+#pragma unroll
+    for (int r = 0; r < 3; r++) dist[r] = fabsf(nr[r]);
+  } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) {   // a real BVH<Triangle>: per-lane walk
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      Ray ray;
+      ray.o = oorg; ray.d = od[r]; ray.b0 = ob0[r]; ray.b1 = ob1[r];
       const Hit mh = mesh_hit<false>(S, o, ray, cnt);
       hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
       pos[r] = v3(0, 0, 0);
       if (mh.hit && xf) { const TriHit th = tri_hit(S.tris[mh.tri], ray); pos[r] = ray_at(ray, th.t); }
-    } else {                                          // one leaf of <= 4 triangles, or List<Triangle>: ordered fold
-      bool bh = false; float bd = 0.0f, bt = 0.0f; uint32_t bi = 0;
-      for (uint32_t t = 0; t < o.ntri; t++) {
-        const TriHit th = tri_hit(S.tris[o.tri_base + t], ray);
-        const bool keep = left_wins(bh, bd, th.hit, th.dist);   // ret = Trace::min(ret, hit)
-        bd = keep ? bd : (th.hit ? th.dist : 0.0f);
-        bt = keep ? bt : (th.hit ? th.t : 0.0f);
-        bi = keep ? bi : (th.hit ? o.tri_base + t : 0u);
-        bh = keep ? bh : th.hit;
+    }
+  } else {                                            // one leaf of <= 4 triangles, or List<Triangle>: ordered fold
+    bool bh[3] = {false, false, false};
+    float bd[3] = {0.0f, 0.0f, 0.0f}, bt[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t bi[3] = {0u, 0u, 0u};
+    for (uint32_t t = 0; t < o.ntri; t++) {
+      TriHit th[3];
+      tri_hit3(S.tris[o.tri_base + t], oorg, od, ob0, ob1, th);
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const bool keep = left_wins(bh[r], bd[r], th[r].hit, th[r].dist);   // ret = Trace::min(ret, hit)
+        bd[r] = keep ? bd[r] : (th[r].hit ? th[r].dist : 0.0f);
+        bt[r] = keep ? bt[r] : (th[r].hit ? th[r].t : 0.0f);
+        bi[r] = keep ? bi[r] : (th[r].hit ? o.tri_base + t : 0u);
+        bh[r] = keep ? bh[r] : th[r].hit;
       }
-      hit[r] = bh; dist[r] = bd; tri[r] = bi;
-      pos[r] = ray_at(ray, bt);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      hit[r] = bh[r]; dist[r] = bd[r]; tri[r] = bi[r];
+      pos[r] = v3(oorg.x + od[r].x * bt[r], oorg.y + od[r].y * bt[r], oorg.z + od[r].z * bt[r]);
     }
   }
   if (xf && __ballot(hit[0] || hit[1] || hit[2]) != 0ull) {
     const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
+    float n2[3], nr[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const V3 p = hit[r] ? pos[r] : oorg;            // lanes without a hit transform a harmless point
-      const float wd = norm(mat_point_uniform(o.trans, p) - ow);
-      dist[r] = hit[r] ? wd : dist[r];
+      n2[r] = norm2(mat_point_uniform(o.trans, p) - ow);
     }
+    const bool miss[3] = {!hit[0], !hit[1], !hit[2]};   // the same point twice: exactly +0
+    sqrt3(n2, miss, nr);
+#pragma unroll
+    for (int r = 0; r < 3; r++) dist[r] = hit[r] ? nr[r] : dist[r];
   }
 }
 
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams
   Rng rng;
   rng.state = 0; rng.inc = 1; rng.draws = 0;
   V3 org = v3(0, 0, 0);
-  V3 d[3] = {v3(0, 0, 1), v3(0, 0, 1), v3(0, 0, 1)};   // bounce: A BSDF direct, B MIS direct, C indirect; burst: 3 camera rays
+  V3 d[3] = {v3(0.25f, 0.5f, 0.75f), v3(0.25f, 0.5f, 0.75f), v3(0.25f, 0.5f, 0.75f)};   // bounce: A BSDF direct, B MIS direct, C indirect; burst: 3 camera rays
   float cb0 = 0.0f, cb1 = 0.0f;                          // dist_bounds shared by the batch: [EPS_F, FLT_MAX] or the camera's [0, inf]
   bool actA = false, actB = false;                       // bounce batch: slots in use (C always); burst: slots 1, 2 in use
   Spec att = spec(0, 0, 0);                              // s1.attenuation (== evaluate(out) for Lambertian)

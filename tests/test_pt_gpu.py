@@ -119,6 +119,56 @@ def test_kernel_math_is_glibc_atan2f(srt):
     pt.close()
 
 
+def _div_sqrt_operands(seed, lanes):
+    """Operands for srt_pt_math_div_sqrt: whole waves inside the fast paths' ranges (with their edges), then waves
+    salted with the values that must send a wave through the full IEEE sequences."""
+    rng = np.random.default_rng(seed)
+    n3 = 3 * lanes
+
+    def mags(lo_e, hi_e, n):
+        m = np.ldexp(1.0 + rng.random(n), rng.integers(lo_e, hi_e, n)).astype(np.float32)
+        return m * rng.choice(np.array([-1.0, 1.0], np.float32), n)
+
+    planes = [mags(-40, 40, n3) for _ in range(4)]            # num0, num1, num2, den in [2^-40, 2^40)
+    x = np.abs(mags(-96, 127, n3))
+    edge = np.array([2.0 ** -40, 2.0 ** 40, -(2.0 ** -40), -(2.0 ** 40), 1.0, 3.0, 1.0 / 3.0], np.float32)
+    for pl in planes:
+        idx = rng.integers(0, n3 // 2, 4096)
+        pl[idx] = rng.choice(edge, 4096)
+    planes[2][rng.integers(0, n3 // 2, 20000)] = 0.0           # numerator of t: origin on the plane
+    planes[2][rng.integers(0, n3 // 2, 2000)] = -0.0
+    x[rng.integers(0, n3 // 2, 20000)] = 0.0
+    x[rng.integers(0, n3 // 2, 4096)] = rng.choice(np.array([2.0 ** -96, 3.4028235e38, 1.0, 2.0, 4.0, 0.25], np.float32), 4096)
+    # second half: specials sprinkled in (about four per wave)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 2.0 ** -41, 2.0 ** 41, 2.0 ** -126, 2.0 ** -100, 2.0 ** 100, 3.4028235e38,
+                        -3.4028235e38, np.inf, -np.inf, np.nan, 2.0 ** -97, 2.0 ** -149, 1.1754942e-38], np.float32)
+    for pl in planes + [x]:
+        idx = rng.integers(n3 // 2, n3, n3 // 96)
+        pl[idx] = rng.choice(special, len(idx))
+    x[rng.integers(n3 // 2, n3, 3000)] = -1.0
+    return planes[0], planes[1], planes[2], planes[3], x
+
+
+def test_exact_division_and_sqrt_fast_paths(srt):
+    """div3x3 / sqrt3 of the wave kernel (refinement shared per denominator, range handling hoisted to one verdict per wave)
+    return the correctly rounded quotient and root for every operand: compared bit for bit with the host's `/` and sqrt."""
+    pt = srt.Pathtracer(0)
+    lanes = 1 << 19
+    for seed, shared in ((21, False), (22, True), (23, True)):
+        n0, n1, n2, den, x = _div_sqrt_operands(seed, lanes)
+        if shared:
+            n2 = np.repeat(n2[0::3], 3)
+        q0, q1, q2, root = pt.math_div_sqrt(n0, n1, n2, den, x, shared_c2=shared)
+        with np.errstate(all="ignore"):
+            want = [n0 / den, n1 / den, n2 / den, np.sqrt(x)]
+        for got, w in zip((q0, q1, q2, root), want):
+            assert w.dtype == np.float32
+            ok = (got.view(np.uint32) == w.view(np.uint32)) | (np.isnan(got) & np.isnan(w))
+            bad = np.flatnonzero(~ok)
+            assert bad.size == 0, (seed, bad[:5], got[bad[:5]], w[bad[:5]])
+    pt.close()
+
+
 def test_delta_lights(srt):
     """Point, spot and directional lights (Pathtracer::point_lighting): the per-lane kernels and the wave kernel's
     shadow batches against the oracle, the shadow rays counted; the builds without point_lighting (flattened walk,
