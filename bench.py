@@ -176,8 +176,21 @@ def traffic_bytes(size, spp, world):
             continue
         wl = doc.get("workload", {})
         if (wl.get("size"), wl.get("spp_per_step"), wl.get("n_gpus")) == (size, spp, world):
-            return doc.get("hbm_bytes_per_launch")
-    return None
+            return doc.get("hbm_bytes_per_launch"), doc
+    return None, None
+
+
+def valu_utilisation(doc, kernel_ms):
+    """The wave kernel is bound by vector-instruction issue, not by HBM or MFMA: wave-instructions per launch (SQ_INSTS_VALU
+    of the committed PMC pass) x the measured issue interval of a SIMD (tools/ubench/pk_rate.hip) / the live launch time."""
+    sq = (doc or {}).get("sq_per_launch") or {}
+    if "SQ_INSTS_VALU" not in sq or not kernel_ms:
+        return None
+    simds = 256 * 4
+    busy_ms = sq["SQ_INSTS_VALU"] / simds * doc["valu_issue_ns"] * 1e-6
+    return {"bound": "valu issue", "wave_instructions_per_launch": sq["SQ_INSTS_VALU"], "issue_ns_per_simd": doc["valu_issue_ns"],
+            "simds": simds, "frac": busy_ms / kernel_ms,
+            "source": "profiles/*_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU ...), tools/ubench/pk_rate.hip"}
 
 
 def main():
@@ -329,6 +342,7 @@ def main():
         mean_radiance = float(acc.mean().item())
         import hashlib
         image_sha = hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()[:16]
+        traffic, prof_doc = traffic_bytes(W, spp, world)
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -346,11 +360,13 @@ def main():
             "mean_radiance": mean_radiance, "image_sha256_16": image_sha,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_bytes(W, spp, world), "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms,
+                "traffic": traffic, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms,
                 "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_launches": wave_launches, "epoch_device_ms": epoch_ms,
                 "algorithmic_bytes_per_ray": bpr,
                 "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
-                "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d)",
+                "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d); "
+                        "the binding resource is vector-instruction issue, see `valu`",
+                "valu": valu_utilisation(prof_doc, kernel_ms),
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -262,7 +262,10 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
 template <bool STAMP, int TRAV, bool DL>
-__global__ __launch_bounds__(256, 4) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+#ifndef SRT_WAVE_OCC
+#define SRT_WAVE_OCC 4
+#endif
+__global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,

@@ -7,7 +7,7 @@ set -e
 tag=${1:-r01_final}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
-mkdir -p "$out"
+rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 8 --warmup 1 --no-cpu-baseline --no-overlap > "$out/stats.log" 2>&1

@@ -63,6 +63,17 @@ def main():
                   "`bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-raster`; FETCH_SIZE doubled per the gfx950 "
                   "note in MI355X_MICROARCH.md; WRITE_SIZE is uncalibrated for this kernel's dword-per-lane stores",
     }
+    # optional: the SQ passes of tools/pmc_sq.sh <tag minus the round prefix> (gpurun_out/pmc_*/{a,b}) -> wave-instruction counts
+    sq_dir = sys.argv[3] if len(sys.argv) > 3 else None
+    if sq_dir:
+        sq = {}
+        for sub, name in (("a", "pmc_sq_a"), ("b", "pmc_sq_b")):
+            path = find(sq_dir, sub, "counter_collection.csv")
+            shutil.copy(path, f"profiles/{tag}_{name}.csv")
+            sq.update(per_launch(path, "pt_wave_kernel")[0])
+        doc["sq_per_launch"] = {k: sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                                                   "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in sq}
+        doc["valu_issue_ns"] = 1.09   # measured: tools/ubench/pk_rate.hip, v_mul_f32 / v_fma_f32 with >= 2 waves per SIMD
     with open(f"profiles/{tag}_traffic.json", "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(doc))

@@ -4,7 +4,7 @@ set -e
 tag=${1:-sq}
 root=$(pwd)
 out=$root/gpurun_out/pmc_$tag
-mkdir -p "$out"
+rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$out/a" -- python3 "$root/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-raster --no-overlap > "$out/a.log" 2>&1
