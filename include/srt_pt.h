@@ -167,6 +167,17 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
  * (order = first vertex index of each triangle in BVH primitive order).  boxes: 6 floats per node,
  * links: {start, size, l, r} per node.  Returns the node count or a negative status. */
 long srt_pt_dump_bvh(srt_pt* pt, int which, float* boxes, uint32_t* links, size_t cap, uint32_t* order);
+/* Tone mapping for display: HDR_Image::tonemap_to (util/hdr_image.cpp:161-187) with Spectrum::to_srgb
+ * (lib/spectrum.h:61-75).  rgb: height*width*3 floats, row 0 first (the accumulated radiance, as srt_pt_render_epoch
+ * returns it); rgba_out: height*width*4 bytes, rows flipped as the reference flips them for display, per channel
+ * (unsigned char)round(to_srgb(1 - exp(-c * exposure)) * 255), alpha 255.  exposure must be positive (the reference
+ * substitutes the image's own exposure for e <= 0; the caller passes that value).  Bit-identical to the reference built
+ * against glibc 2.35 on an x86-64 host with FMA.  The _device form takes device pointers (rgba 4-byte aligned) and
+ * enqueues on `stream` (NULL: the context's stream) without synchronising. */
+int srt_pt_tonemap(srt_pt* pt, const float* rgb, uint32_t width, uint32_t height, float exposure, uint8_t* rgba_out);
+int srt_pt_tonemap_device(srt_pt* pt, void* stream, const float* d_rgb, uint32_t width, uint32_t height, float exposure,
+                          uint8_t* d_rgba);
+
 /* Traversal counters of the LAST srt_pt_trace_samples call (an instrumented launch):
  * {rays, box_tests, objects_entered, tri_tests, sphere_tests, tlas_nodes, blas_nodes, light_tri_tests}. */
 int srt_pt_counters(srt_pt* pt, uint64_t out[8]);
@@ -177,6 +188,9 @@ int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, floa
 /* The kernels' acosf (glibc 2.35's algorithm restated; Samplers::Hemisphere::Uniform) evaluated on the device. */
 int srt_pt_math_acos(srt_pt* pt, const float* x, size_t n, float* out);
 
+/* The epilogue's expf / powf (glibc 2.35's algorithms restated, FMA build) evaluated on the device. */
+int srt_pt_math_exp(srt_pt* pt, const float* x, size_t n, float* out);
+int srt_pt_math_pow(srt_pt* pt, const float* x, const float* y, size_t n, float* out);
 /* The wave kernel's batched IEEE divide / square root (pt_device.h: div3x3, sqrt3) on host operands, called exactly as
  * the batch tests call them: lane i handles operands 3i, 3i+1, 3i+2.  in: five planes of 3*lanes floats (num0, num1,
  * num2, den, x); out: four planes (num0/den, num1/den, num2/den, sqrt(x)).  shared_c2 != 0: a lane's three rays share

@@ -1358,3 +1358,174 @@ int srt_oracle_math_cos_sin(const float* x, size_t n, float* cos_out, float* sin
     for (size_t i = 0; i < n; i++) { cos_out[i] = srt_cosf(x[i]); sin_out[i] = srt_sinf(x[i]); }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SRT-MATH v2, expf / powf: glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c, e_powf.c, e_exp2f_data.c,
+ * e_powf_log2_data.c (the ARM optimized-routines code by Szabolcs Nagy), x86-64 configuration
+ * (TOINT_INTRINSICS 0, hence POWF_SCALE 1 and the 0x1.8p52 shift trick).  fp64 arithmetic, one rounding
+ * to fp32 at the end.  The multiply-adds are FUSED: on an x86-64 host with FMA (every AVX2 machine) glibc's
+ * ifunc selects __expf_fma / __powf_fma, the same source compiled with -mfma, where GCC contracts each a*b+c.
+ * Exhaustive comparison with this host's libm decides it: with fma() the restatement of expf is identical for
+ * every float and powf for every x in [2^-11, 2^9) at y = 5, 10, 7, 3, -4, 2.4 and every x in the sRGB
+ * range at y = 1/2.4; evaluated without FMA, expf differs for 2 of 2^32 arguments and powf for a few in 10^8.
+ * (sinf / cosf above have FMA builds too; over every float of [0, 2pi] and [-1, 1] the unfused restatement
+ * is identical to them.)  The tables were read against __exp2f_data / __powf_log2_data in this image's
+ * libm.so.6; exp2f's is asuint64(2^(i/32)) - (i << 52)/32.  Needed by HDR_Image::tonemap_to
+ * (util/hdr_image.cpp:161-187: 1 - exp(-sample * exposure)) and Spectrum::to_srgb
+ * (lib/spectrum.h:61-66: pow(f, 1/2.4)).  Domain restated: expf for every float; powf for normal x > 0 and
+ * finite y != 0 (to_srgb calls it with 0.0031308 <= x <= 1) - NaN for any other operand.
+ * tests/test_pt_oracle.py compares both with this host's libm.
+ * ---------------------------------------------------------------------------------------------- */
+static const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa,
+    0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+    0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74,
+    0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+    0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069, 0x3fef5818dcfba487, 0x3fef7c97337b9b5f,
+    0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+static const double EXP2F_POLY[3] = {0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
+static uint64_t d_bits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static double bits_d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+static float srt_expf(float x) {
+    const double xd = (double)x;
+    const uint32_t abstop = (f_bits(x) >> 20) & 0x7ff;
+    if (abstop >= 0x42b) {                              /* |x| >= 88 or NaN */
+        if (f_bits(x) == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return bits_f(0x7f800000u);      /* overflow */
+        if (x < -0x1.9fe368p6f) return 0.0f;                    /* underflow to zero */
+    }
+    const double invln2n = 0x1.71547652b82fep+5, shift = 0x1.8p+52;
+    const double c0 = 0x1.c6af84b912394p-20, c1 = 0x1.ebfce50fac4f3p-13, c2 = 0x1.62e42ff0c52d6p-6;   /* poly_scaled */
+    double z = invln2n * xd;
+    double kd = z + shift;
+    const uint64_t ki = d_bits(kd);
+    kd -= shift;
+    const double r = fma(invln2n, xd, -kd);              /* z - kd with the product of z fused in */
+    uint64_t t = EXP2F_TAB[ki % 32];
+    t += ki << (52 - 5);
+    const double s = bits_d(t);
+    z = fma(c0, r, c1);
+    const double r2 = r * r;
+    double y = fma(c2, r, 1.0);
+    y = fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+static const double POWF_LOG2_TAB[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+static const double POWF_LOG2_POLY[5] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2,
+                                         -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp+0};
+static float srt_powf(float x, float y) {
+    const uint32_t ix = f_bits(x), iy = f_bits(y);
+    const uint32_t ay = iy & 0x7fffffffu;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || ay == 0 || ay >= 0x7f800000u) return bits_f(0x7fc00000u);
+    /* log2_inline */
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = POWF_LOG2_TAB[i][0], logc = POWF_LOG2_TAB[i][1];
+    const double z = (double)bits_f(iz);
+    const double r = fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double* A = POWF_LOG2_POLY;
+    const double r2 = r * r;
+    double yy = fma(A[0], r, A[1]);
+    const double p = fma(A[2], r, A[3]);
+    const double r4 = r2 * r2;
+    double q = fma(A[4], r, y0);
+    q = fma(p, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    if (((d_bits(ylogx) >> 47) & 0xffff) >= (d_bits(126.0) >> 47)) {                             /* |y log2 x| >= 126 */
+        if (ylogx > 0x1.fffffffd1d571p+6) return bits_f(0x7f800000u);                            /* overflow */
+        if (ylogx <= -150.0) return 0.0f;                                                        /* underflow */
+    }
+    /* exp2_inline, sign_bias 0 */
+    const double shift = 0x1.8p+47;                       /* 0x1.8p52 / 32 */
+    double kd = ylogx + shift;
+    const uint64_t ki = d_bits(kd);
+    kd -= shift;
+    const double rr = ylogx - kd;
+    uint64_t t = EXP2F_TAB[ki % 32];
+    t += ki << (52 - 5);
+    const double s = bits_d(t);
+    double zz = fma(EXP2F_POLY[0], rr, EXP2F_POLY[1]);
+    const double rr2 = rr * rr;
+    double o = fma(EXP2F_POLY[2], rr, 1.0);
+    o = fma(zz, rr2, o);
+    o = o * s;
+    return (float)o;
+}
+int srt_oracle_math_exp(const float* x, size_t n, float* out) {
+    for (size_t i = 0; i < n; i++) out[i] = srt_expf(x[i]);
+    return 0;
+}
+int srt_oracle_math_pow(const float* x, const float* y, size_t n, float* out) {
+    for (size_t i = 0; i < n; i++) out[i] = srt_powf(x[i], y[i]);
+    return 0;
+}
+/* Brute-force helpers for the tests (the sweeps are too large to ship as arrays): number of floats with bit
+ * patterns in [lo, hi) where the restatement differs from this host's libm (NaN == NaN). */
+uint64_t srt_oracle_sweep_exp_vs_libm(uint32_t lo, uint32_t hi, uint32_t* first_bad) {
+    uint64_t bad = 0;
+    for (uint64_t u = lo; u < hi; u++) {
+        const float x = bits_f((uint32_t)u);
+        const float a = srt_expf(x), b = expf(x);
+        if (f_bits(a) != f_bits(b) && !(a != a && b != b)) { if (!bad && first_bad) *first_bad = (uint32_t)u; bad++; }
+    }
+    return bad;
+}
+uint64_t srt_oracle_sweep_sincos_vs_libm(uint32_t lo, uint32_t hi, uint32_t* first_bad) {
+    uint64_t bad = 0;
+    for (uint64_t u = lo; u < hi; u++) {
+        const float x = bits_f((uint32_t)u);
+        const float a = srt_sinf(x), b = sinf(x), c = srt_cosf(x), d = cosf(x);
+        if (f_bits(a) != f_bits(b) || f_bits(c) != f_bits(d)) { if (!bad && first_bad) *first_bad = (uint32_t)u; bad++; }
+    }
+    return bad;
+}
+uint64_t srt_oracle_sweep_pow_vs_libm(uint32_t lo, uint32_t hi, float y, uint32_t* first_bad) {
+    uint64_t bad = 0;
+    for (uint64_t u = lo; u < hi; u++) {
+        const float x = bits_f((uint32_t)u);
+        const float a = srt_powf(x, y), b = powf(x, y);
+        if (f_bits(a) != f_bits(b) && !(a != a && b != b)) { if (!bad && first_bad) *first_bad = (uint32_t)u; bad++; }
+    }
+    return bad;
+}
+
+/* HDR_Image::tonemap_to (util/hdr_image.cpp:161-187) with Spectrum::to_srgb (lib/spectrum.h:61-75): rows flipped,
+ * 1 - exp(-c * exposure), sRGB transfer, (unsigned char)std::round(c * 255), alpha 255.  rgb: h*w*3 floats, row 0 first.
+ * `exposure` is the image's exposure member, which is what the reference's loop reads (its argument e is unused there). */
+static float to_srgb(float f) {
+    if (f < 0.0031308f) return 12.92f * f;
+    return 1.055f * srt_powf(f, 1.0f / 2.4f) - 0.055f;
+}
+/* (unsigned char)std::round(v * 255.0f) as x86-64 evaluates it: cvttss2si (0x80000000 for NaN / out of range), low byte */
+static unsigned char to_byte(float v) {
+    const float r = roundf(v * 255.0f);
+    const int32_t i = (r >= -2147483648.0f && r < 2147483648.0f) ? (int32_t)r : INT32_MIN;
+    return (unsigned char)((uint32_t)i & 0xffu);
+}
+int srt_oracle_tonemap(uint32_t w, uint32_t h, const float* rgb, float exposure, unsigned char* rgba) {
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t i = 0; i < w; i++) {
+            const float* s = rgb + 3 * ((size_t)(h - j - 1) * w + i);
+            unsigned char* d = rgba + 4 * ((size_t)j * w + i);
+            for (int c = 0; c < 3; c++) d[c] = to_byte(to_srgb(1.0f - srt_expf(-s[c] * exposure)));
+            d[3] = 255;
+        }
+    return 0;
+}

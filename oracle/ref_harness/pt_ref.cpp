@@ -318,6 +318,18 @@ int ref_pt_epoch_rows(void* h, uint64_t seed, uint32_t sample_base, uint32_t sam
   return 0;
 }
 
+// HDR_Image::tonemap_to on caller-supplied radiance.  The reference's loop reads the image's `exposure` MEMBER (what the
+// display path's get_texture(e) leaves behind), not its argument: the harness sets both to the same value.
+int ref_pt_tonemap(uint32_t w, uint32_t h, const float* rgb, float exposure, unsigned char* rgba) {
+  HDR_Image img(w, h);
+  for (size_t i = 0; i < (size_t)w * h; i++) img.at(i) = Spectrum(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+  img.exposure = exposure;
+  std::vector<unsigned char> data;
+  img.tonemap_to(data, exposure);
+  memcpy(rgba, data.data(), data.size());
+  return 0;
+}
+
 // scene.hit for explicit rays: hit flag, distance, position, normal, material (Trace, rays/trace.h).
 int ref_pt_hit(void* h, const float* org, const float* dir, const float* bounds, size_t n, float* out8) {
   RefPT* r = (RefPT*)h;

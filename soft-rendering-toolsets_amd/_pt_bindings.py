@@ -50,6 +50,10 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_math_cos_sin.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
     lib.srt_pt_math_acos.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_math_atan2.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_math_exp.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_math_pow.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_tonemap.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_float, c_void_p]
+    lib.srt_pt_tonemap_device.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_float, c_void_p]
     lib.srt_pt_math_div_sqrt.argtypes = [c_void_p, c_void_p, c_size_t, ctypes.c_int, c_void_p]
     lib.srt_pt_sync.argtypes = [c_void_p]
 
@@ -283,6 +287,29 @@ class Pathtracer:
         y, x = _f32(y), _f32(x)
         out = np.zeros(len(y), np.float32)
         self._check(self._lib, self._lib.srt_pt_math_atan2(self._ctx, _p(y), _p(x), len(y), _p(out)))
+        return out
+
+    def tonemap(self, rgb, exposure: float = 1.0) -> np.ndarray:
+        """HDR_Image::tonemap_to: (h, w, 3) float radiance -> (h, w, 4) uint8 sRGB, rows flipped for display."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        h, w = rgb.shape[:2]
+        out = np.zeros((h, w, 4), np.uint8)
+        self._check(self._lib, self._lib.srt_pt_tonemap(self._ctx, _p(rgb), w, h, float(exposure), _p(out)))
+        return out
+
+    def tonemap_device(self, d_rgb_ptr: int, w: int, h: int, exposure: float, d_rgba_ptr: int, stream: int = 0) -> None:
+        self._check(self._lib, self._lib.srt_pt_tonemap_device(self._ctx, stream or None, d_rgb_ptr, w, h, float(exposure), d_rgba_ptr))
+
+    def math_exp(self, x):
+        x = _f32(x)
+        out = np.zeros(len(x), np.float32)
+        self._check(self._lib, self._lib.srt_pt_math_exp(self._ctx, _p(x), len(x), _p(out)))
+        return out
+
+    def math_pow(self, x, y):
+        x, y = _f32(x), _f32(y)
+        out = np.zeros(len(x), np.float32)
+        self._check(self._lib, self._lib.srt_pt_math_pow(self._ctx, _p(x), _p(y), len(x), _p(out)))
         return out
 
     def math_div_sqrt(self, num0, num1, num2, den, x, shared_c2=False):

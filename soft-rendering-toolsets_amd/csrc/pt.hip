@@ -191,6 +191,28 @@ __global__ void pt_atan2_kernel(const float* __restrict__ y, const float* __rest
   if (i < n) out[i] = srt_atan2f(y[i], x[i]);
 }
 
+// HDR_Image::tonemap_to (util/hdr_image.cpp:161-187): output row j is image row h-1-j; per channel
+// 1 - exp(-c * exposure), Spectrum::to_srgb, (unsigned char)round(c * 255); alpha 255.  One lane per pixel, one packed
+// 32-bit store (consecutive lanes: consecutive pixels of an output row, 12-byte loads / 4-byte stores, fully coalesced).
+__global__ void pt_tonemap_kernel(const float* __restrict__ rgb, uint32_t w, uint32_t h, float exposure, uint32_t* __restrict__ rgba) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)w * h) return;
+  const uint32_t j = (uint32_t)(p / w), i = (uint32_t)(p % w);
+  const float* s = rgb + 3 * ((size_t)(h - j - 1) * w + i);
+  uint32_t px = 0xff000000u;
+#pragma unroll
+  for (int c = 0; c < 3; c++) px |= srgb_byte(to_srgb(1.0f - srt_expf(-s[c] * exposure))) << (8 * c);
+  rgba[p] = px;
+}
+__global__ void pt_exp_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = srt_expf(x[i]);
+}
+__global__ void pt_pow_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = srt_powf(x[i], y[i]);
+}
+
 // Diagnostic for div3x3 / sqrt3 (pt_device.h): lane i takes the operands of "rays" 3i, 3i+1, 3i+2 — exactly how the
 // wave kernel's batch tests call them.  io layout: planes of n3 = 3 * lanes floats: num0, num1, num2, den, x in; q0, q1, q2,
 // root out.  shared_c2: column 2's numerator of a lane is num2[3i] for its three rays (the triangle test's shared t numerator).
@@ -996,6 +1018,73 @@ int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, floa
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
+  return SRT_OK;
+}
+
+int srt_pt_tonemap_device(srt_pt* pt, void* stream, const float* d_rgb, uint32_t width, uint32_t height, float exposure, uint8_t* d_rgba) {
+  int st = need_device(pt, "srt_pt_tonemap_device");
+  if (st != SRT_OK) return st;
+  if (!d_rgb || !d_rgba) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap_device: NULL argument");
+  if (!(exposure > 0.0f)) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap_device: exposure must be positive (got %g)", (double)exposure);
+  if ((reinterpret_cast<uintptr_t>(d_rgba) & 3u) != 0) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap_device: rgba must be 4-byte aligned");
+  const size_t px = (size_t)width * height;
+  if (!px) return SRT_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : pt->stream;
+  pt_tonemap_kernel<<<dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s>>>(d_rgb, width, height, exposure, reinterpret_cast<uint32_t*>(d_rgba));
+  SRT_HIP(hipGetLastError());
+  return SRT_OK;
+}
+
+int srt_pt_tonemap(srt_pt* pt, const float* rgb, uint32_t width, uint32_t height, float exposure, uint8_t* rgba_out) {
+  int st = need_device(pt, "srt_pt_tonemap");
+  if (st != SRT_OK) return st;
+  if (!rgb || !rgba_out) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap: NULL argument");
+  if (!(exposure > 0.0f)) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap: exposure must be positive (got %g)", (double)exposure);
+  const size_t px = (size_t)width * height;
+  if (!px) return SRT_OK;
+  float* d_in = nullptr; uint8_t* d_out = nullptr;
+  SRT_HIP(hipMalloc(&d_in, px * 12));
+  if (hipMalloc(&d_out, px * 4) != hipSuccess) { (void)hipFree(d_in); return srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: out of device memory"); }
+  st = SRT_OK;
+  if (hipMemcpyAsync(d_in, rgb, px * 12, hipMemcpyHostToDevice, pt->stream) != hipSuccess) st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: upload failed");
+  if (st == SRT_OK) st = srt_pt_tonemap_device(pt, nullptr, d_in, width, height, exposure, d_out);
+  if (st == SRT_OK && (hipMemcpyAsync(rgba_out, d_out, px * 4, hipMemcpyDeviceToHost, pt->stream) != hipSuccess ||
+                       hipStreamSynchronize(pt->stream) != hipSuccess))
+    st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: download failed");
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return st;
+}
+
+int srt_pt_math_exp(srt_pt* pt, const float* x, size_t n, float* out) {
+  int st = need_device(pt, "srt_pt_math_exp");
+  if (st != SRT_OK) return st;
+  if (!x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_exp: NULL argument");
+  if (!n) return SRT_OK;
+  float *dx = nullptr, *dout = nullptr;
+  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
+  pt_exp_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, n, dout);
+  SRT_HIP(hipGetLastError());
+  SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  (void)hipFree(dx); (void)hipFree(dout);
+  return SRT_OK;
+}
+
+int srt_pt_math_pow(srt_pt* pt, const float* x, const float* y, size_t n, float* out) {
+  int st = need_device(pt, "srt_pt_math_pow");
+  if (st != SRT_OK) return st;
+  if (!x || !y || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_pow: NULL argument");
+  if (!n) return SRT_OK;
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dy, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
+  SRT_HIP(hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, pt->stream));
+  pt_pow_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, dy, n, dout);
+  SRT_HIP(hipGetLastError());
+  SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
   return SRT_OK;
 }
 

@@ -368,8 +368,102 @@ SRT_DEV double pow2d(float x) { return (double)x * (double)x; }
 SRT_DEV double pow5d(float x) { const double d = (double)x, d2 = d * d, d4 = d2 * d2; return d4 * d; }
 
 // ---------------------------------------------------------------------------------------------------
-// BBox::hit (student/bbox.cpp:5-62): line/slab test; `times` is only narrowed when tmin/tmax fall inside it.
+// SRT-MATH v2, expf / powf: glibc 2.35 e_expf.c / e_powf.c (ARM optimized routines), x86-64 configuration
+// (TOINT_INTRINSICS 0: the 0x1.8p52 shift, POWF_SCALE 1), fp64 with one final rounding.  The multiply-adds are fused
+// as in glibc's FMA builds (__expf_fma / __powf_fma, what an AVX2 host's ifunc selects): with them the restatement is
+// identical to the host libm for every float (expf) and for every normal x at the exponents tried (powf); the
+// unfused forms differ for a handful of arguments.  powf: normal x > 0, finite y != 0, NaN otherwise.
+// Used by the tone-mapping epilogue only (HDR_Image::tonemap_to, Spectrum::to_srgb).
+static __device__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+static __device__ const double kPowfLog2Tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+SRT_DEV uint64_t dbl_bits(double d) { uint64_t u; __builtin_memcpy(&u, &d, 8); return u; }
+SRT_DEV double bits_dbl(uint64_t u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
+// 2^(k/32) * 2^r from ki = bits of (k/32-scaled value + shift): table entry plus the exponent bits of ki
+SRT_DEV double exp2f_scale(uint64_t ki) { return bits_dbl(kExp2fTab[ki % 32] + (ki << 47)); }
+SRT_DEV float srt_expf(float x) {
+  const uint32_t ux = __float_as_uint(x), abstop = (ux >> 20) & 0x7ff;
+  if (abstop >= 0x42b) {                                 // |x| >= 88 or NaN
+    if (ux == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8) return x + x;
+    if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
+    if (x < -0x1.9fe368p6f) return 0.0f;
+  }
+  const double xd = (double)x, invln2n = 0x1.71547652b82fep+5, shift = 0x1.8p+52;
+  const double z = invln2n * xd;
+  double kd = z + shift;
+  const uint64_t ki = dbl_bits(kd);
+  kd -= shift;
+  const double r = __builtin_fma(invln2n, xd, -kd);
+  const double s = exp2f_scale(ki);
+  const double p = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+  const double r2 = r * r;
+  double y = __builtin_fma(0x1.62e42ff0c52d6p-6, r, 1.0);
+  y = __builtin_fma(p, r2, y);
+  return (float)(y * s);
+}
+SRT_DEV float srt_powf(float x, float y) {
+  const uint32_t ix = __float_as_uint(x), ay = __float_as_uint(y) & 0x7fffffffu;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || ay == 0 || ay >= 0x7f800000u) return __uint_as_float(0x7fc00000u);
+  const uint32_t tmp = ix - 0x3f330000u;                 // log2_inline: x = 2^k z, z in [OFF, 2 OFF)
+  const int i = (int)((tmp >> 19) % 16);
+  const uint32_t top = tmp & 0xff800000u;
+  const int k = (int32_t)top >> 23;
+  const double z = (double)__uint_as_float(ix - top);
+  const double r = __builtin_fma(z, kPowfLog2Tab[i][0], -1.0);
+  const double y0 = kPowfLog2Tab[i][1] + (double)k;
+  const double r2 = r * r;
+  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+  const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+  const double r4 = r2 * r2;
+  double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
+  q = __builtin_fma(p, r2, q);
+  yy = __builtin_fma(yy, r4, q);
+  const double ylogx = (double)y * yy;
+  if (((dbl_bits(ylogx) >> 47) & 0xffff) >= (dbl_bits(126.0) >> 47)) {
+    if (ylogx > 0x1.fffffffd1d571p+6) return __uint_as_float(0x7f800000u);
+    if (ylogx <= -150.0) return 0.0f;
+  }
+  const double shift = 0x1.8p+47;                        // exp2_inline
+  double kd = ylogx + shift;
+  const uint64_t ki = dbl_bits(kd);
+  kd -= shift;
+  const double rr = ylogx - kd;
+  const double s = exp2f_scale(ki);
+  const double pz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+  const double rr2 = rr * rr;
+  double o = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+  o = __builtin_fma(pz, rr2, o);
+  return (float)(o * s);
+}
+// Spectrum::to_srgb (lib/spectrum.h:61-66) and the byte conversion of HDR_Image::tonemap_to (util/hdr_image.cpp:181):
+// (unsigned char)std::round(v * 255.0f), i.e. on x86-64 cvttss2si and the low byte (0x80000000 when out of range / NaN).
+SRT_DEV float to_srgb(float f) {
+  if (f < 0.0031308f) return 12.92f * f;
+  return 1.055f * srt_powf(f, 1.0f / 2.4f) - 0.055f;
+}
+SRT_DEV uint32_t srgb_byte(float v) {
+  const float r = roundf(v * 255.0f);
+  const int32_t i = (r >= -2147483648.0f && r < 2147483648.0f) ? (int32_t)r : INT32_MIN;
+  return (uint32_t)i & 0xffu;
+}
+
 // ---------------------------------------------------------------------------------------------------
+// BBox::hit (student/bbox.cpp:5-62): line/slab test; `times` is only narrowed when tmin/tmax fall inside it.
 SRT_DEV bool box_hit(const Node& nd, const Ray& ray, float& tx, float& ty) {
   const float ix = 1.0f / ray.d.x, iy = 1.0f / ray.d.y, iz = 1.0f / ray.d.z;
   const bool sx = ix < 0, sy = iy < 0, sz = iz < 0;

@@ -260,9 +260,28 @@ const HDR_Image& Pathtracer::get_output() {
     return accumulator;
 }
 
-const GL::Tex2D& Pathtracer::get_output_texture(float exposure) {
+void Pathtracer::tonemap_to(std::vector<unsigned char>& data, float exposure) {
     std::lock_guard<std::mutex> lock(accumulator_mut);
-    return accumulator.get_texture(exposure);
+    if(exposure > 0.0f) display_exposure = exposure;
+    auto [w, h] = accumulator.dimension();
+    if(data.size() != w * h * 4) data.resize(w * h * 4);
+    if(w == 0 || h == 0) return;
+    tonemap_in.resize(w * h * 3);
+    const HDR_Image& acc = accumulator;
+    for(size_t i = 0; i < w * h; i++) {
+        const Spectrum s = acc.at(i);
+        tonemap_in[3 * i] = s.r;
+        tonemap_in[3 * i + 1] = s.g;
+        tonemap_in[3 * i + 2] = s.b;
+    }
+    check(srt_pt_tonemap(ctx, tonemap_in.data(), (uint32_t)w, (uint32_t)h, display_exposure, data.data()), "srt_pt_tonemap");
+}
+
+const GL::Tex2D& Pathtracer::get_output_texture(float exposure) {
+    tonemap_to(tonemap_out, exposure);
+    auto [w, h] = accumulator.dimension();
+    output_tex.image((int)w, (int)h, tonemap_out.data());
+    return output_tex;
 }
 
 // Boxes of the BVH<Object> built for the GPU (same node arrays as the reference's, student/bvh.inl:324-372).

@@ -46,6 +46,10 @@ public:
 
     const HDR_Image& get_output();
     const GL::Tex2D& get_output_texture(float exposure);
+    // The accumulator's display bytes, HDR_Image::tonemap_to (util/hdr_image.cpp:161-187) evaluated on the GPU
+    // (srt_pt_tonemap); exposure <= 0 keeps the last one, as HDR_Image::tonemap does.  widgets.cpp:719,863,967 call
+    // pathtracer.get_output().tonemap_to(data, exposure); with the drop-in they call pathtracer.tonemap_to(data, exposure).
+    void tonemap_to(std::vector<unsigned char>& data, float exposure = 0.0f);
     size_t visualize_bvh(GL::Lines& lines, GL::Lines& active, size_t level);
 
     void begin_render(Scene& scene, const Camera& camera, bool add_samples = false);
@@ -68,6 +72,10 @@ private:
     std::atomic<bool> cancel_flag{false};
 
     HDR_Image accumulator;
+    GL::Tex2D output_tex;            // display texture fed by tonemap_to
+    float display_exposure = 1.0f;   // HDR_Image::exposure
+    std::vector<float> tonemap_in;
+    std::vector<unsigned char> tonemap_out;
     std::mutex accumulator_mut;
     size_t total_epochs = 0, accumulator_samples = 0;
     std::atomic<size_t> completed_epochs{0};

@@ -313,3 +313,26 @@ def image_stream(seed, w, h):
     tri = random_triangles(seed + 1, 12, w, h, 50, alpha=(0.3, 0.9))
     prims = np.concatenate([tri[:4], img[:3], tri[4:8], img[3:6], tri[8:], img[6:]])
     return prims, texs
+
+
+def tonemap_image(name, w, h, seed):
+    """Radiance images for the tone-mapping tests: 'render' = an epoch image of the Cornell box out of the path-tracer
+    golden; 'mixed' = seeded values over every branch of HDR_Image::tonemap_to / Spectrum::to_srgb: zeros, values below
+    and around the linear/gamma knee (0.0031308), mid-range, saturating, infinities."""
+    if name == "render":
+        import os
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pt_cbox_64x64_d8_bvh.npz"))
+        ep = np.asarray(g["epoch"], np.float32)
+        assert ep.shape[:2] == (h, w), ep.shape
+        return np.ascontiguousarray(ep[..., :3])
+    rng = np.random.default_rng(seed)
+    n = w * h * 3
+    v = np.exp(rng.uniform(np.log(1e-6), np.log(60.0), n)).astype(np.float32)
+    knee = np.float32(0.0031308)
+    k = rng.integers(0, n, n // 16)
+    v[k] = (knee * (1.0 + rng.uniform(-1e-3, 1e-3, len(k)))).astype(np.float32)     # 1 - exp(-x) ~ x near the knee
+    v[rng.integers(0, n, n // 32)] = 0.0
+    v[rng.integers(0, n, n // 64)] = np.float32(np.inf)
+    v[rng.integers(0, n, n // 64)] = np.float32(200.0)
+    v[rng.integers(0, n, n // 64)] = np.float32(1e-30)
+    return np.ascontiguousarray(v.reshape(h, w, 3))

@@ -476,3 +476,24 @@ class EmuPT(_SceneFeeder):
 
     def close(self):
         self.lib.emu_destroy(self.h_)
+
+
+def oracle_tonemap(rgb, exposure):
+    """HDR_Image::tonemap_to as restated by oracle/pt_oracle.c: (h, w, 3) float32 -> (h, w, 4) uint8."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    out = np.zeros((h, w, 4), np.uint8)
+    oracle().srt_oracle_tonemap(ctypes.c_uint32(w), ctypes.c_uint32(h), P(rgb), ctypes.c_float(exposure), P(out))
+    return out
+
+
+def ref_tonemap(rgb, exposure):
+    """The reference's HDR_Image::tonemap_to (oracle/_ref/libref_pt.so); None when the reference build is absent."""
+    lib = ref_pt_lib()
+    if lib is None:
+        return None
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    out = np.zeros((h, w, 4), np.uint8)
+    lib.ref_pt_tonemap(ctypes.c_uint32(w), ctypes.c_uint32(h), P(rgb), ctypes.c_float(exposure), P(out))
+    return out

@@ -119,6 +119,69 @@ def test_kernel_math_is_glibc_atan2f(srt):
     pt.close()
 
 
+def test_kernel_math_is_glibc_expf_powf(srt):
+    """The epilogue's expf / powf on the device against the oracle's restatement (itself swept against the host libm):
+    random arguments over every exponent, the overflow / underflow edges, the two arguments where an unfused evaluation
+    rounds the other way, and powf over the sRGB range at 1/2.4 and over wide ranges at other exponents."""
+    import ctypes
+
+    pt = srt.Pathtracer(0)
+    rng = np.random.default_rng(31)
+    x = np.concatenate([rng.integers(0, 1 << 32, 2_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+                        -np.exp(rng.uniform(np.log(1e-8), np.log(120.0), 1_000_000)).astype(np.float32),
+                        np.array([0.0, -0.0, 88.0, 88.72284, 88.7229, -103.97, -103.98, -104.5, np.inf, -np.inf, np.nan], np.float32),
+                        np.array([0x4202422f, 0xc27c65d9], np.uint32).view(np.float32)])
+    got = pt.math_exp(x)
+    want = np.zeros_like(x)
+    H.oracle().srt_oracle_math_exp(H.P(x), ctypes.c_size_t(len(x)), H.P(want))
+    assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+    px = np.concatenate([rng.uniform(0.0031308, 1.0, 1_500_000).astype(np.float32),
+                         np.exp(rng.uniform(np.log(1e-30), np.log(1e30), 1_500_000)).astype(np.float32),
+                         np.array([0.0031308, 1.0, 0.5, 1e-45, 0.0, -1.0, np.inf, np.nan], np.float32)])
+    py = np.concatenate([np.full(1_500_000, np.float32(1.0) / np.float32(2.4), np.float32),
+                         rng.uniform(-12.0, 12.0, 1_500_000).astype(np.float32),
+                         np.full(8, np.float32(1.0) / np.float32(2.4), np.float32)])
+    got = pt.math_pow(px, py)
+    want = np.zeros_like(px)
+    H.oracle().srt_oracle_math_pow(H.P(px), H.P(py), ctypes.c_size_t(len(px)), H.P(want))
+    assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+    pt.close()
+
+
+def test_tonemap_matches_reference_golden(srt):
+    """srt_pt_tonemap (HDR_Image::tonemap_to + Spectrum::to_srgb on the device) against the bytes the reference produced
+    (tests/golden/tonemap_*.npz), against the oracle on a larger image with NaN / negative radiance, and the device-pointer
+    form on a torch tensor."""
+    import glob
+    import os
+    import torch
+    from _cases import tonemap_image
+
+    pt = srt.Pathtracer(0)
+    paths = sorted(glob.glob(os.path.join(H.GOLDEN, "tonemap_*.npz")))
+    assert len(paths) >= 4
+    for path in paths:
+        g = np.load(path)
+        assert np.array_equal(pt.tonemap(g["rgb"], float(g["exposure"])), g["rgba"]), os.path.basename(path)
+    rgb = tonemap_image("mixed", 1024, 768, 77)
+    flat = rgb.reshape(-1)
+    rng = np.random.default_rng(78)
+    flat[rng.integers(0, flat.size, 5000)] = np.float32(np.nan)
+    flat[rng.integers(0, flat.size, 5000)] = -np.abs(rng.normal(size=5000)).astype(np.float32)
+    want = H.oracle_tonemap(rgb, 1.7)
+    assert np.array_equal(pt.tonemap(rgb, 1.7), want)
+    d_rgb = torch.from_numpy(rgb).cuda()
+    d_out = torch.zeros((768, 1024, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    pt.tonemap_device(d_rgb.data_ptr(), 1024, 768, 1.7, d_out.data_ptr())
+    pt.sync()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    with pytest.raises(srt.SrtError):
+        pt.tonemap(rgb, 0.0)
+    assert pt.tonemap(np.zeros((0, 0, 3), np.float32), 1.0).shape == (0, 0, 4)
+    pt.close()
+
+
 def _div_sqrt_operands(seed, lanes):
     """Operands for srt_pt_math_div_sqrt: whole waves inside the fast paths' ranges (with their edges), then waves
     salted with the values that must send a wave through the full IEEE sequences."""

@@ -78,6 +78,14 @@ def test_host_only_context_refuses_to_render(srt):
     pt.close()
 
 
+def test_host_only_context_refuses_to_tonemap(srt):
+    pt = srt.Pathtracer(device=-1)
+    with pytest.raises(srt.SrtError) as e:
+        pt.tonemap(np.zeros((4, 4, 3), np.float32), 1.0)
+    assert e.value.status == -2 and "no CPU fallback" in str(e.value)
+    pt.close()
+
+
 def test_scene_argument_checks(srt):
     pt = srt.Pathtracer(device=-1)
     from soft_rendering_toolsets_amd import scenes

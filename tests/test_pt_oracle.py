@@ -130,6 +130,58 @@ def test_srt_math_acos_is_glibc():
         assert out[i].view(np.uint32) == np.float32(libm.acosf(float(x[i]))).view(np.uint32), float(x[i])
 
 
+TONEMAP_GOLDENS = sorted(glob.glob(os.path.join(H.GOLDEN, "tonemap_*.npz")))
+
+
+def test_srt_math_exp_pow_are_glibc():
+    """expf / powf of SRT-MATH v2 (FMA build of glibc 2.35's algorithms) against this host's libm: a strided sweep of every
+    exponent range of expf and the whole sRGB argument range of powf at y = 1/2.4 (the complete sweeps - every float for
+    expf, every normal x at eight exponents for powf - were run when the restatement was written; see oracle/pt_oracle.c)."""
+    lib = H.oracle()
+    lib.srt_oracle_sweep_exp_vs_libm.restype = ctypes.c_uint64
+    lib.srt_oracle_sweep_pow_vs_libm.restype = ctypes.c_uint64
+    first = ctypes.c_uint32(0)
+    bad = 0
+    for start in range(0, 1 << 32, 1 << 26):                # 64 windows of 2^17 consecutive floats, all exponents, both signs
+        bad += lib.srt_oracle_sweep_exp_vs_libm(ctypes.c_uint32(start), ctypes.c_uint32(start + (1 << 17)), ctypes.byref(first))
+    bad += lib.srt_oracle_sweep_exp_vs_libm(ctypes.c_uint32(0xc2b00000), ctypes.c_uint32(0xc2d00000), ctypes.byref(first))   # -88 .. -104
+    bad += lib.srt_oracle_sweep_exp_vs_libm(ctypes.c_uint32(0x4202422f), ctypes.c_uint32(0x42024230), ctypes.byref(first))   # unfused forms fail here
+    bad += lib.srt_oracle_sweep_exp_vs_libm(ctypes.c_uint32(0xc27c65d9), ctypes.c_uint32(0xc27c65da), ctypes.byref(first))
+    assert bad == 0, hex(first.value)
+    lo = int(np.float32(0.0031308).view(np.uint32)) - 64
+    hi = int(np.float32(1.0).view(np.uint32)) + 64
+    y = ctypes.c_float(float(np.float32(1.0) / np.float32(2.4)))
+    assert lib.srt_oracle_sweep_pow_vs_libm(ctypes.c_uint32(lo), ctypes.c_uint32(hi), y, ctypes.byref(first)) == 0, hex(first.value)
+    for yy in (2.4, 5.0, 10.0, -1.5):
+        assert lib.srt_oracle_sweep_pow_vs_libm(ctypes.c_uint32(0x3e000000), ctypes.c_uint32(0x3e000000 + (1 << 22)), ctypes.c_float(yy),
+                                                ctypes.byref(first)) == 0, (yy, hex(first.value))
+
+
+@pytest.mark.parametrize("path", TONEMAP_GOLDENS, ids=[os.path.basename(g)[8:-4] for g in TONEMAP_GOLDENS])
+def test_oracle_tonemap_matches_reference_golden(path):
+    g = np.load(path)
+    assert np.array_equal(H.oracle_tonemap(g["rgb"], float(g["exposure"])), g["rgba"])
+
+
+def test_tonemap_goldens_present():
+    assert len(TONEMAP_GOLDENS) >= 4
+
+
+@pytest.mark.skipif(H.ref_pt_lib() is None, reason="reference build (oracle/_ref) not present")
+def test_oracle_tonemap_matches_reference_build():
+    """Fresh seeded images, negative radiance and NaN included (their byte goes through the float -> unsigned char cast the
+    way x86-64 compiles it), against the reference's HDR_Image::tonemap_to itself."""
+    from _cases import tonemap_image
+
+    for seed, exposure in ((101, 1.0), (102, 0.8), (103, 3.0)):
+        rgb = tonemap_image("mixed", 96, 64, seed)
+        rng = np.random.default_rng(seed)
+        flat = rgb.reshape(-1)
+        flat[rng.integers(0, flat.size, 200)] = np.float32(np.nan)
+        flat[rng.integers(0, flat.size, 200)] = -np.abs(rng.normal(size=200)).astype(np.float32)
+        assert np.array_equal(H.oracle_tonemap(rgb, exposure), H.ref_tonemap(rgb, exposure))
+
+
 def test_accumulate_running_mean():
     rng = np.random.default_rng(3)
     acc = np.zeros(300, np.float32)
