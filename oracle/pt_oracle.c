@@ -118,8 +118,10 @@ static int rng_coin(ctx_t* c, float p) { return rng_unit(c) < p; }
  * third-party dependency of the reference (not under /root/reference); the constants below are the
  * published ones and were checked against __sincosf_table in this image's libm.so.6
  * (Ubuntu GLIBC 2.35-0ubuntu3.11).  Evaluated without FMA, the restatement is bit-identical to
- * glibc's sinf/cosf on 2e8 random arguments in [0, 2pi] and [-1, 1] (the only ranges this renderer
- * uses: phi = 2*pi*xi and theta = cos(angle)); tests/test_pt_oracle.py repeats that check.
+ * glibc's sinf/cosf (whose ifunc picks the FMA build on this host) for EVERY float in [0, 2pi] and
+ * [-1, 1] - the only ranges this renderer uses: phi = 2*pi*xi and theta = cos(angle) - by the
+ * exhaustive sweep srt_oracle_sweep_sincos_vs_libm; tests/test_pt_oracle.py repeats it on samples.
+ * (Beyond 2pi the unfused form differs from the FMA build for 17 floats below 120.)
  * |x| >= 120 would need glibc's reduce_large; the renderer never gets there and NaN is returned.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; } sincos_tab;
