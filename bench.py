@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--no-elision", action="store_true", help="skip the extra pass that measures dead-ray elision")
     ap.add_argument("--no-overlap", action="store_true", help="every step on one stream (no overlap of consecutive launches)")
     args = ap.parse_args()
 
@@ -328,6 +329,42 @@ def main():
     else:
         kernel_ms_max, total_rays, total_cams = kernel_ms, rays, cams
 
+    main_sha = main_mean = None
+    if rank == 0:
+        import hashlib
+        main_sha = hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()
+        main_mean = float(acc.mean().item())
+    elision = None
+    if world == 1 and not args.no_elision:
+        # Second pass with dead-ray elision (include/srt_pt.h: srt_pt_set_elision): the headline above traces EVERY ray the
+        # reference issues; here the wave kernel skips the BSDF-sampled direct ray whose term the reference adds and subtracts
+        # again (legal, both ray counts reported).  Same steps, fresh accumulator, image compared.
+        full_sha = main_sha
+        pt.set_elision(True)
+        acc_done[0] = None
+        step(0, False)
+        torch.cuda.synchronize()
+        pt.ray_count(reset=True); pt.rays_elided(reset=True)
+        acc.zero_()
+        acc_done[0] = None
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, False)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        rays2, cams2 = pt.ray_count(reset=True)
+        elided = pt.rays_elided(reset=True)
+        elision = {
+            "in_value": False, "ms_per_step": el2 * 1e3 / args.steps, "camera_samples_per_s": cams2 / el2,
+            "reference_equivalent_mrays_per_s": rays2 / el2 / 1e6, "traced_mrays_per_s": (rays2 - elided) / el2 / 1e6,
+            "rays_elided_fraction": elided / max(1, rays2),
+            "image_equals_full_trace_bit_for_bit": hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest() == full_sha,
+            "note": "two-ray batches: the BSDF-sampled direct ray of a Lambertian bounce is provably dead without delta / "
+                    "environment lights ((0 + d) - d == +0); its random draws are kept, the ray is not traced",
+        }
+        pt.set_elision(False)
+
     if rank == 0:
         # traversal averages of this workload from an instrumented launch (outside the timed region)
         rng = np.random.default_rng(1)
@@ -339,9 +376,8 @@ def main():
         bpr = bytes_per_ray(cnt)
         rays_per_launch_rank0 = rays / args.steps
         achieved = bpr * rays_per_launch_rank0 / (kernel_ms * 1e-3) / 1e9
-        mean_radiance = float(acc.mean().item())
-        import hashlib
-        image_sha = hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()[:16]
+        mean_radiance = main_mean
+        image_sha = main_sha[:16]
         traffic, prof_doc = traffic_bytes(W, spp, world)
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
@@ -369,6 +405,8 @@ def main():
                 "valu": valu_utilisation(prof_doc, kernel_ms),
             },
         }
+        if elision is not None:
+            out["dead_ray_elision"] = elision
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt)
         if not args.no_raster and world == 1:

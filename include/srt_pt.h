@@ -156,6 +156,16 @@ int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launc
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);
 
 /* ---- parity / inspection -------------------------------------------------------------------------- */
+/* Dead-ray elision.  In sample_direct_lighting the reference adds the term of the BSDF-sampled
+ * direct ray and subtracts it again (student/pathtracer.cpp:118-125): without delta / environment lights the ray cannot
+ * change the result of a Lambertian bounce (its random draws are still consumed).  on != 0 lets the wave-uniform kernel
+ * skip tracing it (two-ray batches) where that is provable - no delta or environment light, every continuous BSDF
+ * Lambertian, sweep build; other scenes and kernels ignore the switch.  The image is bit-identical either way.
+ * srt_pt_ray_count keeps counting the rays the REFERENCE issues; srt_pt_rays_elided reports how many of them were not
+ * traced.  Default: off (every ray traced). */
+int srt_pt_set_elision(srt_pt* pt, int on);
+int srt_pt_rays_elided(srt_pt* pt, uint64_t* elided, int reset);
+
 /* trace_pixel for explicit (x, y, sample) triples (host arrays of n).  rgb_out: 3 floats per sample;
  * draws_out / rays_out (nullable): RNG draws and scene.hit calls of that sample. */
 int srt_pt_trace_samples(srt_pt* pt, uint64_t seed, const uint32_t* xs, const uint32_t* ys, const uint32_t* ss,

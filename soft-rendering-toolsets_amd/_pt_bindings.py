@@ -50,6 +50,8 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_math_cos_sin.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
     lib.srt_pt_math_acos.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_math_atan2.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_set_elision.argtypes = [c_void_p, c_int]
+    lib.srt_pt_rays_elided.argtypes = [c_void_p, POINTER(c_uint64), c_int]
     lib.srt_pt_math_exp.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_math_pow.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_tonemap.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_float, c_void_p]
@@ -288,6 +290,15 @@ class Pathtracer:
         out = np.zeros(len(y), np.float32)
         self._check(self._lib, self._lib.srt_pt_math_atan2(self._ctx, _p(y), _p(x), len(y), _p(out)))
         return out
+
+    def set_elision(self, on: bool) -> None:
+        """Let the wave kernel skip the provably dead BSDF-sampled direct ray (include/srt_pt.h); images stay bit-identical."""
+        self._check(self._lib, self._lib.srt_pt_set_elision(self._ctx, int(bool(on))))
+
+    def rays_elided(self, reset: bool = False) -> int:
+        n = c_uint64(0)
+        self._check(self._lib, self._lib.srt_pt_rays_elided(self._ctx, ctypes.byref(n), int(reset)))
+        return int(n.value)
 
     def tonemap(self, rgb, exposure: float = 1.0) -> np.ndarray:
         """HDR_Image::tonemap_to: (h, w, 3) float radiance -> (h, w, 4) uint8 sRGB, rows flipped for display."""

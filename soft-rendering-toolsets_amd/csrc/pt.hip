@@ -213,7 +213,7 @@ __global__ void pt_pow_kernel(const float* __restrict__ x, const float* __restri
   if (i < n) out[i] = srt_powf(x[i], y[i]);
 }
 
-// Diagnostic for div3x3 / sqrt3 (pt_device.h): lane i takes the operands of "rays" 3i, 3i+1, 3i+2 — exactly how the
+// Diagnostic for divNx3 / sqrtN (pt_device.h): lane i takes the operands of "rays" 3i, 3i+1, 3i+2 — exactly how the
 // wave kernel's batch tests call them.  io layout: planes of n3 = 3 * lanes floats: num0, num1, num2, den, x in; q0, q1, q2,
 // root out.  shared_c2: column 2's numerator of a lane is num2[3i] for its three rays (the triangle test's shared t numerator).
 __global__ void pt_div_sqrt_kernel(const float* __restrict__ in, size_t lanes, int shared_c2, float* __restrict__ out) {
@@ -230,8 +230,8 @@ __global__ void pt_div_sqrt_kernel(const float* __restrict__ in, size_t lanes, i
     x[r] = in[4 * n3 + k + r];
     zero[r] = __float_as_uint(x[r]) == 0u;
   }
-  if (shared_c2) div3x3<true>(num, den, q); else div3x3<false>(num, den, q);
-  sqrt3(x, zero, root);
+  if (shared_c2) divNx3<3, true>(num, den, q); else divNx3<3, false>(num, den, q);
+  sqrtN<3>(x, zero, root);
   if (i < lanes) {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -281,7 +281,8 @@ struct srt_pt {
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
-  unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 1 slot: rays of the epoch kernels
+  unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
+  int elide = 0;                            // srt_pt_set_elision
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
   // srt_pt_kernel_time: event pairs recorded around the dominant kernel's launches, on the launch stream
@@ -418,11 +419,17 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const int trav = wave_trav(pt);
   const bool stamp = pt->kernel_mode == 3;
   const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
-  const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * 6 * 64 * sizeof(float);  // 4 waves x (Q - 1) x 3 rays x 2 fields
   const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
-  const void* kern = stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false> : (const void*)pt_wave_kernel<true, 2, false>)
-                     : dl  ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, true> : (const void*)pt_wave_kernel<false, 1, true>)
-                           : (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false> : trav == 1 ? (const void*)pt_wave_kernel<false, 1, false> : (const void*)pt_wave_kernel<false, 2, false>);
+  // two-ray batches (dead BSDF-sampled direct ray not traced): asked for, sweep build, no delta / environment light, and
+  // every continuous BSDF Lambertian (pt_wave.h)
+  bool two = pt->elide && !stamp && !dl && trav != 2;
+  for (const Material& m : F.materials)                 // a light material that does not emit would be shaded as a continuous non-Lambertian BSDF
+    if (m.type == 3u && !(0.2126f * m.a[0] + 0.7152f * m.a[1] + 0.0722f * m.a[2] > 0.0f)) two = false;
+  const uint32_t burst = two ? 2u : kBurst;
+  const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);  // 4 waves x (Q - 1) x rays x 2 fields
+  const void* kern = two ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false, 2> : (const void*)pt_wave_kernel<false, 1, false, 2>) : stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false, 3> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false, 3> : (const void*)pt_wave_kernel<true, 2, false, 3>)
+                     : dl  ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, true, 3> : (const void*)pt_wave_kernel<false, 1, true, 3>)
+                           : (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false, 3> : trav == 1 ? (const void*)pt_wave_kernel<false, 1, false, 3> : (const void*)pt_wave_kernel<false, 2, false, 3>);
   if (pt->wave_blocks == 0 || pt->wave_lds != lds || pt->wave_mode != pt->kernel_mode || pt->wave_kern != kern) {
     pt->wave_mode = pt->kernel_mode;
     pt->wave_kern = kern;
@@ -450,15 +457,15 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     WaveParams P;
     P.T = T; P.seed = seed; P.sample_base = sample_base + done; P.samples = n;
-    P.singles = (n >= 4 * kBurst) ? kBurst + n % kBurst : n % kBurst;   // 3..5 of a big launch's samples per pixel, else the remainder
+    P.singles = (n >= 4 * burst) ? burst + n % burst : n % burst;   // 3..5 of a big launch's samples per pixel, else the remainder
     // small shards (<= 64 samples per resident lane, e.g. 1/4 or 1/8 of the bench image): a longer run of short items
     // at the end shortens the tail by more than the singles cost (8.9 vs 9.1 ms for a 1/8 shard)
-    if (n >= 8 * kBurst && (uint64_t)px * n <= 64ull * nlanes) P.singles += 2 * kBurst;
-    if (getenv("SRT_WAVE_SINGLES") && n >= 4 * kBurst) {   // experiments: more single-sample units at the tail
+    if (n >= 8 * burst && (uint64_t)px * n <= 64ull * nlanes) P.singles += 2 * burst;
+    if (getenv("SRT_WAVE_SINGLES") && n >= 4 * burst) {   // experiments: more single-sample units at the tail
       const uint32_t want = (uint32_t)atoi(getenv("SRT_WAVE_SINGLES"));
-      if (want < n) P.singles = want - (want % kBurst) + n % kBurst;
+      if (want < n) P.singles = want - (want % burst) + n % burst;
     }
-    P.groups3 = (n - P.singles) / kBurst;
+    P.groups3 = (n - P.singles) / burst;
     P.units3 = px * P.groups3;
     P.total_units = px * (P.groups3 + P.singles); P.nlanes = nlanes;
     P.sample_out = B.d_samples; P.records = B.d_records;
@@ -468,19 +475,20 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.chunk = getenv("SRT_WAVE_CHUNK") ? (uint32_t)atoi(getenv("SRT_WAVE_CHUNK")) : kChunk;
     P.flat_ready = getenv("SRT_FLAT_READY") ? (uint32_t)atoi(getenv("SRT_FLAT_READY")) : kFlatReady;
     P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;
-    P.queue_head = B.d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.stamps = B.d_queue + 1;
+    P.queue_head = B.d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1; P.stamps = B.d_queue + 1;
     if (n) {
       SRT_HIP(hipMemsetAsync(B.d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt);
-#define SRT_LAUNCH_WAVE(STAMP_, TRAV_, DL_)                                                                                   \
-  pt_wave_kernel<STAMP_, TRAV_, DL_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm,       \
+#define SRT_LAUNCH_WAVE(STAMP_, TRAV_, DL_, NR_)                                                                              \
+  pt_wave_kernel<STAMP_, TRAV_, DL_, NR_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm,       \
                                                                                    DS.nodes, DS.lights, DS.light_tris,          \
                                                                                    DS.materials, DS.wave_tlas, DS.blas_recs,    \
                                                                                    P.records, P.sample_out)
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
-      if (stamp) { if (trav == 0) SRT_LAUNCH_WAVE(true, 0, false); else if (trav == 1) SRT_LAUNCH_WAVE(true, 1, false); else SRT_LAUNCH_WAVE(true, 2, false); }
-      else if (dl) { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, true); else SRT_LAUNCH_WAVE(false, 1, true); }
-      else { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, false); else if (trav == 1) SRT_LAUNCH_WAVE(false, 1, false); else SRT_LAUNCH_WAVE(false, 2, false); }
+      if (two) { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, false, 2); else SRT_LAUNCH_WAVE(false, 1, false, 2); }
+      else if (stamp) { if (trav == 0) SRT_LAUNCH_WAVE(true, 0, false, 3); else if (trav == 1) SRT_LAUNCH_WAVE(true, 1, false, 3); else SRT_LAUNCH_WAVE(true, 2, false, 3); }
+      else if (dl) { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, true, 3); else SRT_LAUNCH_WAVE(false, 1, true, 3); }
+      else { if (trav == 0) SRT_LAUNCH_WAVE(false, 0, false, 3); else if (trav == 1) SRT_LAUNCH_WAVE(false, 1, false, 3); else SRT_LAUNCH_WAVE(false, 2, false, 3); }
 #undef SRT_LAUNCH_WAVE
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
@@ -539,8 +547,8 @@ int srt_pt_create(int device, srt_pt** out) {
     }
     if (device >= count) { delete pt; return srt::fail(SRT_ERR_INVALID, "device %d out of range [0,%d)", device, count); }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pt->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&pt->d_totals, (C_COUNT + 1) * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(pt->d_totals, 0, (C_COUNT + 1) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&pt->d_totals, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(pt->d_totals, 0, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess) {
       delete pt;
       return srt::fail(SRT_ERR_HIP, "HIP context setup failed on device %d", device);
     }
@@ -886,6 +894,24 @@ int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int r
     SRT_HIP(hipMemset(pt->d_totals + C_COUNT, 0, sizeof r));
     pt->camera_samples = 0;
   }
+  return SRT_OK;
+}
+
+int srt_pt_set_elision(srt_pt* pt, int on) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_elision: NULL context");
+  pt->elide = on ? 1 : 0;
+  pt->wave_blocks = 0;                                    // the launch configuration is re-derived for the other build
+  return SRT_OK;
+}
+
+int srt_pt_rays_elided(srt_pt* pt, uint64_t* elided, int reset) {
+  int st = need_device(pt, "srt_pt_rays_elided");
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipDeviceSynchronize());
+  unsigned long long r = 0;
+  SRT_HIP(hipMemcpy(&r, pt->d_totals + C_COUNT + 1, sizeof r, hipMemcpyDeviceToHost));
+  if (elided) *elided = r;
+  if (reset) SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 1, 0, sizeof r));
   return SRT_OK;
 }
 

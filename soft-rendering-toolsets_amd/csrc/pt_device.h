@@ -33,7 +33,7 @@ struct Ray { V3 o, d; float b0, b1; };
 // exponent range: v_div_scale returns its input, VCC = 0, v_div_fixup and the sqrt fix-ups pass the result
 // through) what remains is the refinement itself, and the part of it that only depends on the denominator can
 // be shared by the quotients of one triangle test (u, v, t over det) or one normalisation (x, y, z over the norm).
-// Used by the wave kernel's batch tests only (three rays at a time, so the serial refinement chains overlap).
+// Used by the wave kernel's batch tests only (two or three rays at a time, so the serial refinement chains overlap).
 // The fast path is taken when the whole wave qualifies; any other operand sends the wave through the compiler's
 // own sequence, so the results are those of the plain `/` and sqrtf for every input
 // (tests/test_pt_gpu.py::test_exact_division_and_sqrt_fast_paths sweeps both against them).
@@ -52,18 +52,19 @@ SRT_DEV float div_refine(float num, float den, float r) {
   return __builtin_fmaf(e2, r, q);
 }
 #endif
-// Three square roots / nine quotients (the three rays of a batch): one range verdict for all operands, and the
+// N square roots / 3 N quotients (the N rays of a batch): one range verdict for all operands, and the
 // refinement chains of the three rays are independent instruction streams inside one basic block.
 // zero[r] = "x[r] is exactly +0" as the caller knows it (origin on the triangle's plane: t = 0; a ray without a hit:
 // distance of a point from itself): v_sqrt(0) = 0 and neither correction applies, so a zero may take the fast path.
-SRT_DEV void sqrt3(const float* x, const bool* zero, float* o) {
+template <int N>
+SRT_DEV void sqrtN(const float* x, const bool* zero, float* o) {
 #if SRT_EXACT_FAST_PATHS
   bool bad = false;
 #pragma unroll
-  for (int r = 0; r < 3; r++) bad = bad || (!zero[r] && !(x[r] >= 0x1p-96f && x[r] <= FLT_MAX));
+  for (int r = 0; r < N; r++) bad = bad || (!zero[r] && !(x[r] >= 0x1p-96f && x[r] <= FLT_MAX));
   if (__ballot(bad) == 0ull) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < N; r++) {
       const float s = __builtin_amdgcn_sqrtf(x[r]);
       const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
       const float rm = __builtin_fmaf(-sm, s, x[r]), rp = __builtin_fmaf(-sp, s, x[r]);
@@ -75,19 +76,20 @@ SRT_DEV void sqrt3(const float* x, const bool* zero, float* o) {
   }
 #endif
 #pragma unroll
-  for (int r = 0; r < 3; r++) o[r] = sqrtf(x[r]);
+  for (int r = 0; r < N; r++) o[r] = sqrtf(x[r]);
 }
-// q[r][j] = n[r][j] / den[r].  SHARED_C2: the caller passes the same numerator in column 2 for the three rays (the
+// q[r][j] = n[r][j] / den[r].  SHARED_C2: the caller passes the same numerator in column 2 for all rays (the
 // numerator of t), which is exactly zero for an origin on the triangle's plane; such a lane takes the fast path as
 // well and v_div_fixup gives the signed zero the full sequence would.
-template <bool SHARED_C2>
-SRT_DEV void div3x3(const float (*n)[3], const float* den, float (*q)[3]) {
+template <int N, bool SHARED_C2>
+SRT_DEV void divNx3(const float (*n)[3], const float* den, float (*q)[3]) {
 #if SRT_EXACT_FAST_PATHS
   const float lo = 0x1p-40f, hi = 0x1p40f;     // quotient exponents stay within +-80: no scaling case of v_div_scale
-  float mn = fminf(fminf(fabsf(den[0]), fabsf(den[1])), fabsf(den[2]));
-  float mx = fmaxf(fmaxf(fabsf(den[0]), fabsf(den[1])), fabsf(den[2]));
+  float mn = fabsf(den[0]), mx = fabsf(den[0]);
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 1; r < N; r++) { mn = fminf(mn, fabsf(den[r])); mx = fmaxf(mx, fabsf(den[r])); }
+#pragma unroll
+  for (int r = 0; r < N; r++) {
     if (SHARED_C2) {
       mn = fminf(mn, fminf(fabsf(n[r][0]), fabsf(n[r][1])));
       mx = fmaxf(mx, fmaxf(fabsf(n[r][0]), fabsf(n[r][1])));
@@ -103,7 +105,7 @@ SRT_DEV void div3x3(const float (*n)[3], const float* den, float (*q)[3]) {
   // (min / max skip a NaN operand: it stays a NaN through the refinement, as it would through the full sequence)
   if (__ballot(!(mn >= lo && mx <= hi)) == 0ull) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < N; r++) {
       float rc = __builtin_amdgcn_rcpf(den[r]);
       const float e = __builtin_fmaf(-den[r], rc, 1.0f);
       rc = __builtin_fmaf(e, rc, rc);
@@ -115,7 +117,7 @@ SRT_DEV void div3x3(const float (*n)[3], const float* den, float (*q)[3]) {
   }
 #endif
 #pragma unroll
-  for (int r = 0; r < 3; r++)
+  for (int r = 0; r < N; r++)
 #pragma unroll
     for (int j = 0; j < 3; j++) q[r][j] = n[r][j] / den[r];
 }
@@ -511,30 +513,33 @@ SRT_DEV TriHit tri_hit(const Tri& g, const Ray& ray) {
   return h;
 }
 
-// Triangle::hit of one triangle for the three rays of a batch (shared origin): s, s x e2 and the numerator of t do
-// not depend on the direction; the nine quotients and the three distances go through div3x3 / sqrt3.
-SRT_DEV void tri_hit3(const Tri& g, V3 org, const V3* d, const float* b0, const float* b1, TriHit* h) {
+// Triangle::hit of one triangle for the N rays of a batch (shared origin): s, s x e2 and the numerator of t do
+// not depend on the direction; the 3 N quotients and the N distances go through divNx3 / sqrtN.
+template <int N>
+SRT_DEV void tri_hitN(const Tri& g, V3 org, const V3* d, const float* b0, const float* b1, TriHit* h) {
   const V3 e1 = v3p(g.e1), e2 = v3p(g.e2);
   const V3 s = org - v3p(g.p0);
   const V3 sxe2 = cross(s, e2);
   const float nt = -1.0f * dot(sxe2, e1);
-  float num[3][3], det[3], q[3][3], n2[3], nr[3];
+  float num[N][3], det[N], q[N][3], n2[N], nr[N];
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < N; r++) {
     const V3 e1xd = cross(e1, d[r]);
     det[r] = dot(e1xd, e2);
     num[r][0] = -1.0f * dot(sxe2, d[r]);
     num[r][1] = dot(e1xd, s);
     num[r][2] = nt;
   }
-  div3x3<true>(num, det, q);
+  divNx3<N, true>(num, det, q);
 #pragma unroll
-  for (int r = 0; r < 3; r++) n2[r] = norm2(d[r] * q[r][2]);
-  const bool on_plane = nt == 0.0f;             // t = +-0 for the three rays: the distances are exactly +0
-  const bool zero[3] = {on_plane, on_plane, on_plane};
-  sqrt3(n2, zero, nr);
+  for (int r = 0; r < N; r++) n2[r] = norm2(d[r] * q[r][2]);
+  const bool on_plane = nt == 0.0f;             // t = +-0 for every ray: the distances are exactly +0
+  bool zero[N];
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < N; r++) zero[r] = on_plane;
+  sqrtN<N>(n2, zero, nr);
+#pragma unroll
+  for (int r = 0; r < N; r++) {
     h[r].u = q[r][0]; h[r].v = q[r][1]; h[r].t = q[r][2];
     const bool outside = (h[r].u < 0) || (h[r].v < 0) || ((1.0f - h[r].u - h[r].v) < 0) || (h[r].t < 0);
     h[r].dist = fabsf(nr[r]);

@@ -44,7 +44,7 @@ namespace srt {
 
 constexpr uint32_t kWaveMaxObjects = 16;
 constexpr uint32_t kChunk = 64;           // units (sample triples) a wave reserves per queue atomic (WaveParams::chunk)
-constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit
+constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit (2 in the two-ray build)
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
 constexpr uint32_t kFlatReady = 16;        // TRAV 2: lanes with a finished batch that make the wave leave the walk
 constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
@@ -61,7 +61,8 @@ struct WaveParams {
   float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
   float* records;            // [(level * kRecFields + f) * nlanes + lane]
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
-  unsigned long long* ray_counter;  // scene.hit calls, accumulated across launches
+  unsigned long long* ray_counter;  // scene.hit calls as the reference issues them, accumulated across launches
+  unsigned long long* elided_counter;  // of those, the rays the two-ray build did not have to trace
   unsigned long long* stamps;
   uint32_t chunk;            // units a wave reserves per queue atomic
   uint32_t npix;             // pixel slots of the launch; sample_out is [sample][pixel slot] so that the reduction reads coalesced
@@ -151,52 +152,55 @@ SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, 
 // world distance Trace::transform recomputes, and the winning triangle (global index).
 // HAS_BLAS = false compiles the per-lane BVH<Triangle> walk out (the host picks that build when every mesh is a
 // single leaf, e.g. the Cornell box): the walk's registers would otherwise halve the occupancy of the common path.
-template <bool HAS_BLAS>
-SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
+template <bool HAS_BLAS, int NR>
+SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
                           Counters& cnt, bool* hit, float* dist, uint32_t* tri) {
   const Object& o = S.objects[k];
   const bool xf = o.has_trans != 0;
   V3 oorg = org;
-  V3 od[3] = {d[0], d[1], d[2]};
-  float ob0[3] = {rb0[0], rb0[1], rb0[2]}, ob1[3] = {rb1[0], rb1[1], rb1[2]};
+  V3 od[NR];
+  float ob0[NR], ob1[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) { od[r] = d[r]; ob0[r] = rb0[r]; ob1[r] = rb1[r]; }
   if (xf) {                                           // Ray::transform with the shared origin
     oorg = mat_point_uniform(o.itrans, org);
-    float n2[3], dn[3], num[3][3], q[3][3];
+    float n2[NR], dn[NR], num[NR][3], q[NR][3];
+    bool nz[NR];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       const V3 rd = mat_rotate(o.itrans, d[r]);
       num[r][0] = rd.x; num[r][1] = rd.y; num[r][2] = rd.z;
       n2[r] = norm2(rd);
+      nz[r] = false;
     }
-    const bool nz[3] = {false, false, false};
-    sqrt3(n2, nz, dn);
-    div3x3<false>(num, dn, q);
+    sqrtN<NR>(n2, nz, dn);
+    divNx3<NR, false>(num, dn, q);
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       ob0[r] *= dn[r]; ob1[r] *= dn[r];
       od[r] = v3(q[r][0], q[r][1], q[r][2]);
     }
   }
-  V3 pos[3];
+  V3 pos[NR];
   if (o.kind == OBJ_SPHERE) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       Ray ray;
       ray.o = oorg; ray.d = od[r]; ray.b0 = ob0[r]; ray.b1 = ob1[r];
       const SphHit sh = sphere_hit(o.radius, ray);
       hit[r] = sh.hit; tri[r] = 0;
       pos[r] = ray_at(ray, sh.t);
     }
-    float n2[3], nr[3];
+    float n2[NR], nr[NR];
+    bool miss[NR];                                    // no hit: t = 0, pos == origin
 #pragma unroll
-    for (int r = 0; r < 3; r++) n2[r] = norm2(pos[r] - oorg);
-    const bool miss[3] = {!hit[0], !hit[1], !hit[2]};   // no hit: t = 0, pos == origin
-    sqrt3(n2, miss, nr);
+    for (int r = 0; r < NR; r++) { n2[r] = norm2(pos[r] - oorg); miss[r] = !hit[r]; }
+    sqrtN<NR>(n2, miss, nr);
 #pragma unroll
-    for (int r = 0; r < 3; r++) dist[r] = fabsf(nr[r]);
+    for (int r = 0; r < NR; r++) dist[r] = fabsf(nr[r]);
   } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) {   // a real BVH<Triangle>: per-lane walk
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       Ray ray;
       ray.o = oorg; ray.d = od[r]; ray.b0 = ob0[r]; ray.b1 = ob1[r];
       const Hit mh = mesh_hit<false>(S, o, ray, cnt);
@@ -205,14 +209,16 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       if (mh.hit && xf) { const TriHit th = tri_hit(S.tris[mh.tri], ray); pos[r] = ray_at(ray, th.t); }
     }
   } else {                                            // one leaf of <= 4 triangles, or List<Triangle>: ordered fold
-    bool bh[3] = {false, false, false};
-    float bd[3] = {0.0f, 0.0f, 0.0f}, bt[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t bi[3] = {0u, 0u, 0u};
-    for (uint32_t t = 0; t < o.ntri; t++) {
-      TriHit th[3];
-      tri_hit3(S.tris[o.tri_base + t], oorg, od, ob0, ob1, th);
+    bool bh[NR];
+    float bd[NR], bt[NR];
+    uint32_t bi[NR];
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) { bh[r] = false; bd[r] = 0.0f; bt[r] = 0.0f; bi[r] = 0u; }
+    for (uint32_t t = 0; t < o.ntri; t++) {
+      TriHit th[NR];
+      tri_hitN<NR>(S.tris[o.tri_base + t], oorg, od, ob0, ob1, th);
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
         const bool keep = left_wins(bh[r], bd[r], th[r].hit, th[r].dist);   // ret = Trace::min(ret, hit)
         bd[r] = keep ? bd[r] : (th[r].hit ? th[r].dist : 0.0f);
         bt[r] = keep ? bt[r] : (th[r].hit ? th[r].t : 0.0f);
@@ -221,23 +227,27 @@ SRT_DEV void object_test3(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       }
     }
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       hit[r] = bh[r]; dist[r] = bd[r]; tri[r] = bi[r];
       pos[r] = v3(oorg.x + od[r].x * bt[r], oorg.y + od[r].y * bt[r], oorg.z + od[r].z * bt[r]);
     }
   }
-  if (xf && __ballot(hit[0] || hit[1] || hit[2]) != 0ull) {
-    const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
-    float n2[3], nr[3];
+  bool any = false;
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < NR; r++) any = any || hit[r];
+  if (xf && __ballot(any) != 0ull) {
+    const V3 ow = mat_point_uniform(o.trans, oorg);   // Trace::transform: distance = |T*position - T*origin|
+    float n2[NR], nr[NR];
+    bool miss[NR];                                    // the same point twice: exactly +0
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
       const V3 p = hit[r] ? pos[r] : oorg;            // lanes without a hit transform a harmless point
       n2[r] = norm2(mat_point_uniform(o.trans, p) - ow);
+      miss[r] = !hit[r];
     }
-    const bool miss[3] = {!hit[0], !hit[1], !hit[2]};   // the same point twice: exactly +0
-    sqrt3(n2, miss, nr);
+    sqrtN<NR>(n2, miss, nr);
 #pragma unroll
-    for (int r = 0; r < 3; r++) dist[r] = hit[r] ? nr[r] : dist[r];
+    for (int r = 0; r < NR; r++) dist[r] = hit[r] ? nr[r] : dist[r];
   }
 }
 
@@ -261,7 +271,13 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // STAMP = true is a diagnostic build: s_memtime deltas of the loop's sections are summed per wave and added to
 // P.stamps (never used for results or for reported times; the stamps themselves perturb the schedule).
 enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_TERMINATE, ST_COUNT_ };
-template <bool STAMP, int TRAV, bool DL>
+// NR = rays per batch.  3: the batch described above.  2: the build for scenes without delta / environment lights whose
+// continuous BSDFs are all Lambertian.  There the BSDF-sampled direct ray of sample_direct_lighting is dead: the reference
+// adds its term and subtracts it again (student/pathtracer.cpp:118-125: radiance = (point_lighting + direct) - direct with
+// point_lighting == 0, i.e. +0 for any finite direct, and a NaN direct comes with a NaN second term), so only its random
+// draws are kept and a bounce batch is {MIS direct ray | the direct ray of a discrete BSDF, indirect ray}; units are
+// pairs of samples.  Rays are counted as the reference issues them (P.ray_counter); P.elided_counter counts the ones not traced.
+template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC
 #define SRT_WAVE_OCC 4
 #endif
@@ -271,6 +287,8 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
                                                       const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
                                                       float* __restrict__ a_records, float* __restrict__ a_samples) {
+  static_assert(NR == 3 || (NR == 2 && TRAV != 2 && !DL), "two-ray batches: sweep builds without delta / environment lights only");
+  constexpr int C = NR - 1;                              // slot of the indirect ray
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
@@ -294,12 +312,13 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
   //   after step q            field 0 = cur_far_t.x of node q        (tin is dead once read)
   //   after bottom-up step q  field 0 = ret.dist, field 1 = ret.id   (read by the parent)
   // The root (q = 0) has no slot: it receives no `times` and nobody reads its result; its cur_far_t.x stays in registers.
-  float* wl = lds_f + (size_t)wave * (Q > 0 ? Q - 1 : 0) * 6 * 64 + lane;
-#define SLOT(q, r, f) wl[((((q) - 1) * 3 + (r)) * 2 + (f)) * 64]
+  float* wl = lds_f + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;
+#define SLOT(q, r, f) wl[((((q) - 1) * NR + (r)) * 2 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
   Counters cnt;
   cnt.v[C_RAYS] = 0;
+  uint32_t traced = 0;                                   // rays this lane actually traced (== cnt.v[C_RAYS] when NR == 3)
 
   // ---- persistent per-lane path state ----
   bool alive = false;                                    // the lane owns a unit that is not finished yet
@@ -307,12 +326,16 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
   uint32_t px = 0, py = 0;                               // pixel of the unit
   uint32_t s_first = 0, s_count = 0, s_cur = 0;          // samples [s_first, s_first + s_count) of the launch; current one
   uint32_t pixel_slot = 0;                               // local pixel index (sample_out addressing)
-  uint32_t pend[2] = {kRetMiss, kRetMiss};               // parked camera hits of samples s_cur+1, s_cur+2 (burst order)
+  uint32_t pend[NR - 1];                                 // parked camera hits of samples s_cur+1, s_cur+2 (burst order)
+#pragma unroll
+  for (int j = 0; j < NR - 1; j++) pend[j] = kRetMiss;
   uint32_t depth = 0, level = 0;
   Rng rng;
   rng.state = 0; rng.inc = 1; rng.draws = 0;
   V3 org = v3(0, 0, 0);
-  V3 d[3] = {v3(0.25f, 0.5f, 0.75f), v3(0.25f, 0.5f, 0.75f), v3(0.25f, 0.5f, 0.75f)};   // bounce: A BSDF direct, B MIS direct, C indirect; burst: 3 camera rays
+  V3 d[NR];                                              // bounce: A BSDF direct, B MIS direct, C indirect (NR == 2: direct, indirect); burst: camera rays
+#pragma unroll
+  for (int j = 0; j < NR; j++) d[j] = v3(0.25f, 0.5f, 0.75f);
   float cb0 = 0.0f, cb1 = 0.0f;                          // dist_bounds shared by the batch: [EPS_F, FLT_MAX] or the camera's [0, inf]
   bool actA = false, actB = false;                       // bounce batch: slots in use (C always); burst: slots 1, 2 in use
   Spec att = spec(0, 0, 0);                              // s1.attenuation (== evaluate(out) for Lambertian)
@@ -367,8 +390,8 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
         // the end of the launch does not wait for a lane that drew three long paths)
         const uint32_t g3 = opq(P.groups3), g1 = opq(P.singles), n3 = opq(P.units3), img_w = opq(S.w), img_h = opq(S.h);
         uint32_t u_pixel, u_first, u_count;
-        if (my_unit < n3) { u_pixel = my_unit / g3; u_first = (my_unit % g3) * kBurst; u_count = kBurst; }
-        else { const uint32_t v = my_unit - n3; u_pixel = v / g1; u_first = g3 * kBurst + v % g1; u_count = 1u; }
+        if (my_unit < n3) { u_pixel = my_unit / g3; u_first = (my_unit % g3) * (uint32_t)NR; u_count = (uint32_t)NR; }
+        else { const uint32_t v = my_unit - n3; u_pixel = v / g1; u_first = g3 * (uint32_t)NR + v % g1; u_count = 1u; }
         unit_pixel(opq(P.T), u_pixel, x, y);
         if (x < img_w && y < img_h) {                   // padding pixels of edge tiles are never read
           alive = true;
@@ -385,7 +408,7 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
           const uint64_t seed = opq(P.seed);
           const uint32_t sample_base = opq(P.sample_base);
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
+          for (int j = 0; j < NR; j++) {
             const uint32_t sj = s_first + ((uint32_t)j < s_count ? (uint32_t)j : 0u);
             rng.key(seed, y * img_w + x, sample_base + sj);
             const float jx = rng.unit() * 1.0f;
@@ -409,14 +432,24 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
     if (TRAV != 2) {
       if (DL && sh_phase) cnt.v[C_RAYS] += alive ? (1u + (sa1 ? 1u : 0u) + (sa2 ? 1u : 0u)) : 0u;
-      else cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
+      else if (NR == 3) cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
+      else {
+        // a burst traces its samples' camera rays; a bounce traces two rays where the reference issues three (continuous) or two
+        cnt.v[C_RAYS] += alive ? (burst ? (1u + (actA ? 1u : 0u)) : (discrete ? 2u : 3u)) : 0u;
+        traced += alive ? (burst ? (1u + (actA ? 1u : 0u)) : 2u) : 0u;
+      }
     }
     const bool shb = DL && sh_phase;
-    const float rb0[3] = {cb0, cb0, cb0};
-    const float rb1[3] = {shb ? sb1[0] : cb1, shb ? sb1[1] : cb1, shb ? sb1[2] : cb1};
-    Hit res[3];
+    float rb0[NR], rb1[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) { rb0[r] = cb0; rb1[r] = cb1; }
+    if constexpr (DL) {
+#pragma unroll
+      for (int r = 0; r < NR; r++) rb1[r] = shb ? sb1[r] : cb1;
+    }
+    Hit res[NR];
     bool batch_ready = alive;                            // the lane's batch has been traced completely
-    if (TRAV == 2) {
+    if constexpr (TRAV == 2) {
       // general scenes: one flattened per-lane walk over both tree levels for the slots that carry a ray
       if (need_begin) {
         cnt.v[C_RAYS] += 1u + (actA ? 1u : 0u) + (actB ? 1u : 0u);
@@ -430,20 +463,21 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
     } else if (Q == 0) {
       // List<Object>::hit, or a BVH<Object> whose root is a leaf: ordered fold over every object
 #pragma unroll
-      for (int r = 0; r < 3; r++) res[r] = no_hit();
+      for (int r = 0; r < NR; r++) res[r] = no_hit();
       for (uint32_t k = 0; k < nobj; k++) {
-        bool h[3]; float dd[3]; uint32_t tt[3];
-        object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+        bool h[NR]; float dd[NR]; uint32_t tt[NR];
+        object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
-        for (int r = 0; r < 3; r++) fold(res[r], h[r], dd[r], k, tt[r]);
+        for (int r = 0; r < NR; r++) fold(res[r], h[r], dd[r], k, tt[r]);
       }
     } else {
-      V3 inv[3];
-      float tx0[3], ty0[3];
-      unsigned long long fl[3] = {0ull, 0ull, 0ull};
-      float farx0[3] = {0.0f, 0.0f, 0.0f};
+      V3 inv[NR];
+      float tx0[NR], ty0[NR];
+      unsigned long long fl[NR];
+      float farx0[NR];
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
+      for (int r = 0; r < NR; r++) {
+        fl[r] = 0ull; farx0[r] = 0.0f;
         inv[r] = v3(1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z);
         const float dn = norm(d[r]);
         tx0[r] = rb0[r] / dn; ty0[r] = rb1[r] / dn;   // Vec2 time_initial = dist_bounds / dir.norm()
@@ -452,7 +486,7 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
       for (uint32_t q = 0; q < Q; q++) {
         const WaveInterior& W = S.wave_tlas[q];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < NR; r++) {
           float tx = tx0[r], ty = ty0[r];
           if (q != 0) { tx = SLOT(q, r, 0); ty = SLOT(q, r, 1); }
           float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
@@ -475,38 +509,38 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
       // bottom-up: leaves are evaluated in place, interior children read back, then the visit rule + Trace::min
       for (int q = (int)Q - 1; q >= 0; q--) {
         const WaveInterior& W = S.wave_tlas[q];
-        Hit L[3], R[3];
+        Hit L[NR], R[NR];
         if (W.l_ref >= 0) {
 #pragma unroll
-          for (int r = 0; r < 3; r++) L[r] = unpack_ret(SLOT(W.l_ref, r, 0), __float_as_uint(SLOT(W.l_ref, r, 1)));
+          for (int r = 0; r < NR; r++) L[r] = unpack_ret(SLOT(W.l_ref, r, 0), __float_as_uint(SLOT(W.l_ref, r, 1)));
         } else {
 #pragma unroll
-          for (int r = 0; r < 3; r++) L[r] = no_hit();
+          for (int r = 0; r < NR; r++) L[r] = no_hit();
           const uint32_t first = (uint32_t)~W.l_ref;
           for (uint32_t k = first; k < first + W.l_cnt; k++) {
-            bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            bool h[NR]; float dd[NR]; uint32_t tt[NR];
+            object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
-            for (int r = 0; r < 3; r++) fold(L[r], h[r], dd[r], k, tt[r]);
+            for (int r = 0; r < NR; r++) fold(L[r], h[r], dd[r], k, tt[r]);
           }
         }
         if (W.r_ref >= 0) {
 #pragma unroll
-          for (int r = 0; r < 3; r++) R[r] = unpack_ret(SLOT(W.r_ref, r, 0), __float_as_uint(SLOT(W.r_ref, r, 1)));
+          for (int r = 0; r < NR; r++) R[r] = unpack_ret(SLOT(W.r_ref, r, 0), __float_as_uint(SLOT(W.r_ref, r, 1)));
         } else {
 #pragma unroll
-          for (int r = 0; r < 3; r++) R[r] = no_hit();
+          for (int r = 0; r < NR; r++) R[r] = no_hit();
           const uint32_t first = (uint32_t)~W.r_ref;
           for (uint32_t k = first; k < first + W.r_cnt; k++) {
-            bool h[3]; float dd[3]; uint32_t tt[3];
-            object_test3<TRAV == 1>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            bool h[NR]; float dd[NR]; uint32_t tt[NR];
+            object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
 #pragma unroll
-            for (int r = 0; r < 3; r++) fold(R[r], h[r], dd[r], k, tt[r]);
+            for (int r = 0; r < NR; r++) fold(R[r], h[r], dd[r], k, tt[r]);
           }
         }
         SECTION_END(ST_LEAVES)
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < NR; r++) {
           const uint32_t f = (uint32_t)(fl[r] >> (4 * q)) & 15u;
           const bool cl = (f & 4u) != 0;
           const Hit rc = cl ? L[r] : R[r];
@@ -530,40 +564,65 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
     if (batch_ready) {
       uint32_t chit = kRetMiss;                         // packed closest hit that decides how the current path goes on
       bool more_shadow = false;                         // another batch goes out before the path is resolved
-      if (DL && sh_phase) {
-        // a shadow batch returned: radiance += attenuation * sample.radiance for the unoccluded lights, in light order
+      bool shadow_returned = false;
+      if constexpr (DL) {
+        if (sh_phase) {
+          shadow_returned = true;
+          // a shadow batch returned: radiance += attenuation * sample.radiance for the unoccluded lights, in light order
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          if (light_i + (uint32_t)j < S.ndelta) {
-            const LightSample ls = delta_light_sample(S.delta_lights[light_i + (uint32_t)j], org);
-            if (!res[j].hit) pl = pl + att * ls.radiance;
+          for (int j = 0; j < NR; j++) {
+            if (light_i + (uint32_t)j < S.ndelta) {
+              const LightSample ls = delta_light_sample(S.delta_lights[light_i + (uint32_t)j], org);
+              if (!res[j].hit) pl = pl + att * ls.radiance;
+            }
+          }
+          light_i += 3u;
+          if (light_i < S.ndelta) more_shadow = true;
+          else {
+            Spec radiance = pl;                         // sample_direct_lighting, student/pathtracer.cpp:78-172
+            radiance = radiance + dA_keep;
+            radiance = radiance - dA_keep;
+            radiance = radiance + d6_keep;
+            float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
+            rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+            sh_phase = false;
+            chit = held_chit;
+            d[C] = dC_keep;
           }
         }
-        light_i += 3u;
-        if (light_i < S.ndelta) more_shadow = true;
-        else {
-          Spec radiance = pl;                           // sample_direct_lighting, student/pathtracer.cpp:78-172
-          radiance = radiance + dA_keep;
-          radiance = radiance - dA_keep;
-          radiance = radiance + d6_keep;
-          float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-          rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
-          sh_phase = false;
-          chit = held_chit;
-          d[2] = dC_keep;
-        }
+      }
+      if (shadow_returned) {
       } else if (burst) {
-        // burst order: slot 0 = sample s_first (continues now), slots 1, 2 = the next samples (parked)
+        // burst order: slot 0 = sample s_first (continues now), the other slots = the next samples (parked)
         chit = pack_ret(res[0]);
-        pend[0] = pack_ret(res[1]);
-        pend[1] = pack_ret(res[2]);
-        if (DL && S.env_type != 0u) {
-          // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
-          // whether evaluate(dir) is the radiance or zero, the directions are gone when the parked samples are resolved
-          if (!res[0].hit && (S.env_type == 1u || d[0].y > 0.0f)) chit = kRetMissEnv;
-          if (!res[1].hit && (S.env_type == 1u || d[1].y > 0.0f)) pend[0] = kRetMissEnv;
-          if (!res[2].hit && (S.env_type == 1u || d[2].y > 0.0f)) pend[1] = kRetMissEnv;
+#pragma unroll
+        for (int j = 0; j < NR - 1; j++) pend[j] = pack_ret(res[j + 1]);
+        if constexpr (DL) {
+          if (S.env_type != 0u) {
+            // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
+            // whether evaluate(dir) is the radiance or zero, the directions are gone when the parked samples are resolved
+            if (!res[0].hit && (S.env_type == 1u || d[0].y > 0.0f)) chit = kRetMissEnv;
+#pragma unroll
+            for (int j = 0; j < NR - 1; j++)
+              if (!res[j + 1].hit && (S.env_type == 1u || d[j + 1].y > 0.0f)) pend[j] = kRetMissEnv;
+          }
         }
+      } else if constexpr (NR == 2) {
+        // slot 0 = the direct ray that matters: discrete BSDF -> the BSDF-sampled one, else the MIS one (see the head comment)
+        Spec e0 = spec(0, 0, 0);
+        if (res[0].hit) { const Spec e = emissive_of(S.materials[S.objects[res[0].obj].material]); if (luma(e) > 0.0f) e0 = e; }
+        Spec radiance = spec(0, 0, 0);
+        if (discrete) {
+          const Spec direct = e0 * att;
+          radiance = radiance + direct;
+        } else {
+          const float pdf = (pdf4 + pdf_area) / 2.0f;
+          const Spec d6 = (e0 * att) * (1.0f / pdf);
+          radiance = radiance + d6;                     // ((0 + direct) - direct) + d6
+        }
+        float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
+        rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+        chit = pack_ret(res[C]);
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
           Spec eA = spec(0, 0, 0), eB = spec(0, 0, 0);
@@ -582,7 +641,7 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
             if (DL && S.ndelta != 0u && luma(att) != 0.0f) {
               // point_lighting comes first in the sum: hold the two terms until the shadow rays are back
               dA_keep = direct; d6_keep = d6; pl = spec(0, 0, 0);
-              light_i = 0; held_chit = pack_ret(res[2]); dC_keep = d[2];
+              light_i = 0; held_chit = pack_ret(res[C]); dC_keep = d[C];
               sh_phase = true; more_shadow = true;
             } else {
               radiance = radiance + direct;
@@ -595,19 +654,21 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
             rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
           }
         }
-        chit = pack_ret(res[2]);
+        chit = pack_ret(res[C]);
       }
-      if (DL && more_shadow) {
-        // next shadow batch: lights light_i .. light_i + 2 (Ray(hit.pos, sample.direction, {EPS_F, distance - EPS_F}))
+      if constexpr (DL) {
+        if (more_shadow) {
+          // next shadow batch: lights light_i .. light_i + 2 (Ray(hit.pos, sample.direction, {EPS_F, distance - EPS_F}))
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const uint32_t li = light_i + (uint32_t)j < S.ndelta ? light_i + (uint32_t)j : light_i;
-          const LightSample ls = delta_light_sample(S.delta_lights[li], org);
-          d[j] = unit(ls.direction);
-          sb1[j] = ls.distance - kEps;
+          for (int j = 0; j < NR; j++) {
+            const uint32_t li = light_i + (uint32_t)j < S.ndelta ? light_i + (uint32_t)j : light_i;
+            const LightSample ls = delta_light_sample(S.delta_lights[li], org);
+            d[j] = unit(ls.direction);
+            sb1[j] = ls.distance - kEps;
+          }
+          sa1 = light_i + 1u < S.ndelta; sa2 = light_i + 2u < S.ndelta;
+          if (TRAV == 2) need_begin = true;
         }
-        sa1 = light_i + 1u < S.ndelta; sa2 = light_i + 2u < S.ndelta;
-        if (TRAV == 2) need_begin = true;
       }
       SECTION_END(ST_POST)
       // Resolve the current path; when it ends, the next parked camera hit (if any) takes over in the same cycle.
@@ -643,7 +704,8 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
         s_cur++;
         if (s_cur < s_first + s_count) {
           chit = pend[0];
-          pend[0] = pend[1];
+#pragma unroll
+          for (int j = 0; j + 1 < NR - 1; j++) pend[j] = pend[j + 1];
           level = 0;
           depth = S.max_depth;
           burst = true;                                 // "the ray that led here was a camera ray"
@@ -656,7 +718,7 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
         const Material& m = S.materials[mi];
         const Hit ch = unpack_ret(0.0f, chit);
         Ray ray;
-        ray.o = org; ray.d = d[2]; ray.b0 = cb0; ray.b1 = cb1;
+        ray.o = org; ray.d = d[C]; ray.b0 = cb0; ray.b1 = cb1;
         if (level == 0) {
           // a camera ray: regenerate it (and the RNG position after its two jitter draws) from the sample index
           const uint32_t img_w = opq(S.w), img_h = opq(S.h);
@@ -703,9 +765,13 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
         level++;
         depth--;
         org = sf.position;
-        d[0] = unit(world_in);                         // explicit Ray(point, dir, ...) normalizes
-        d[1] = unit(chosen);
-        d[2] = unit(world_in2);
+        if constexpr (NR == 3) {
+          d[0] = unit(world_in);                       // explicit Ray(point, dir, ...) normalizes
+          d[1] = unit(chosen);
+        } else {
+          d[0] = unit(discrete ? world_in : chosen);   // the BSDF-sampled direct ray of a continuous BSDF is not traced
+        }
+        d[C] = unit(world_in2);
         cb0 = kEps; cb1 = FLT_MAX;
         need_begin = true;
       }
@@ -717,9 +783,9 @@ __global__ __launch_bounds__(256, SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in,
 #undef SECTION_END
 
 #undef SLOT
-  unsigned long long r = cnt.v[C_RAYS];
-  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-  if (lane == 0) atomicAdd(P.ray_counter, r);
+  unsigned long long r = cnt.v[C_RAYS], rt = (NR == 3) ? cnt.v[C_RAYS] : traced;
+  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); }
+  if (lane == 0) { atomicAdd(P.ray_counter, r); if (NR == 2) atomicAdd(P.elided_counter, r - rt); }
 }
 
 // Adds the samples of each pixel in sample order with do_trace's validity filter.  A render of more than one

