@@ -158,9 +158,10 @@ int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int r
 /* ---- parity / inspection -------------------------------------------------------------------------- */
 /* Dead-ray elision.  In sample_direct_lighting the reference adds the term of the BSDF-sampled
  * direct ray and subtracts it again (student/pathtracer.cpp:118-125): without delta / environment lights the ray cannot
- * change the result of a Lambertian bounce (its random draws are still consumed).  on != 0 lets the wave-uniform kernel
- * skip tracing it (two-ray batches) where that is provable - no delta or environment light, every continuous BSDF
- * Lambertian, sweep build; other scenes and kernels ignore the switch.  The image is bit-identical either way.
+ * change the result of a Lambertian bounce (its random draws are still consumed).  on != 0 lets the kernels skip tracing
+ * it where that is provable - no delta or environment light, every continuous BSDF Lambertian: the wave-uniform kernel
+ * then runs two-ray batches, the per-lane kernels skip the call; other scenes (and the flattened-walk and stamped
+ * diagnostic builds) ignore the switch.  The image is bit-identical either way.
  * srt_pt_ray_count keeps counting the rays the REFERENCE issues; srt_pt_rays_elided reports how many of them were not
  * traced.  Default: off (every ray traced). */
 int srt_pt_set_elision(srt_pt* pt, int on);

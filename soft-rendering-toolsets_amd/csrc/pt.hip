@@ -70,9 +70,9 @@ __global__ __launch_bounds__(64) void pt_epoch_kernel(DScene S, TileMap T, uint6
   if (sampled > 0) acc = acc * (1.0f / sampled);
   out[0] = acc.r; out[1] = acc.g; out[2] = acc.b;
   if (ray_counter) {  // one atomic per wavefront (every lane of the wave reaches this point)
-    unsigned long long r = cnt.v[C_RAYS];
-    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(ray_counter, r);
+    unsigned long long r = cnt.v[C_RAYS], e = cnt.elided;
+    for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); e += __shfl_down(e, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(ray_counter, r); if (e) atomicAdd(ray_counter + 1, e); }
   }
 }
 
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(64, 8) void pt_unit_kernel(DScene S, TileMap T, uin
       reinterpret_cast<float4*>(sample_out)[(size_t)(u % samples) * (total_units / samples) + u / samples] = make_float4(p.r, p.g, p.b, 0.0f);
     }
   }
-  unsigned long long r = cnt.v[C_RAYS];
-  for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-  if ((threadIdx.x & 63) == 0 && r) atomicAdd(ray_counter, r);
+  unsigned long long r = cnt.v[C_RAYS], e = cnt.elided;
+  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); e += __shfl_down(e, off); }
+  if ((threadIdx.x & 63) == 0 && r) { atomicAdd(ray_counter, r); if (e) atomicAdd(ray_counter + 1, e); }
 }
 
 // Explicit (x, y, sample) triples; instrumented when COUNT.
@@ -318,6 +318,17 @@ int need_ready(srt_pt* pt, const char* what) {
   return SRT_OK;
 }
 
+// srt_pt_set_elision asked for it and the BSDF-sampled direct ray of every continuous bounce is provably dead in this scene:
+// no delta light, no environment light, and no light material without emission (it would be shaded as a continuous,
+// non-Lambertian BSDF).  include/srt_pt.h, pt_wave.h.
+bool elision_provable(const srt_pt* pt) {
+  const FlatScene& F = pt->built.flat;
+  if (!pt->elide || !F.delta_lights.empty() || pt->env_type != 0) return false;
+  for (const Material& m : F.materials)
+    if (m.type == 3u && !(0.2126f * m.a[0] + 0.7152f * m.a[1] + 0.0722f * m.a[2] > 0.0f)) return false;
+  return true;
+}
+
 DScene device_scene(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   DScene S;
@@ -330,6 +341,7 @@ DScene device_scene(const srt_pt* pt) {
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size();
   S.tlas_nodes = F.tlas_nodes; S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;
   S.cam = pt->cam; S.w = pt->w; S.h = pt->h; S.max_depth = pt->max_depth;
+  S.elide = elision_provable(pt) ? 1u : 0u;
   return S;
 }
 
@@ -422,9 +434,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
   // two-ray batches (dead BSDF-sampled direct ray not traced): asked for, sweep build, no delta / environment light, and
   // every continuous BSDF Lambertian (pt_wave.h)
-  bool two = pt->elide && !stamp && !dl && trav != 2;
-  for (const Material& m : F.materials)                 // a light material that does not emit would be shaded as a continuous non-Lambertian BSDF
-    if (m.type == 3u && !(0.2126f * m.a[0] + 0.7152f * m.a[1] + 0.0722f * m.a[2] > 0.0f)) two = false;
+  const bool two = elision_provable(pt) && !stamp && trav != 2;
   const uint32_t burst = two ? 2u : kBurst;
   const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);  // 4 waves x (Q - 1) x rays x 2 fields
   const void* kern = two ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false, 2> : (const void*)pt_wave_kernel<false, 1, false, 2>) : stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false, 3> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false, 3> : (const void*)pt_wave_kernel<true, 2, false, 3>)

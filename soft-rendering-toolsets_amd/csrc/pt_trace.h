@@ -34,13 +34,14 @@ struct DScene {
   uint32_t nobjects, nlights, tlas_nodes, use_bvh, light_tri_first;
   Camera cam;
   uint32_t w, h, max_depth;
+  uint32_t elide;                  // srt_pt_set_elision and the proof holds for this scene: the dead direct ray is not traced
 };
 
 // Image-tile shard of one rank: tiles t with t % world == rank, numbered row-major.
 struct TileMap { uint32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, local_tiles; };
 
 enum { C_RAYS = 0, C_BOX, C_OBJ, C_TRI, C_SPH, C_TLAS, C_BLAS, C_LTRI, C_COUNT };
-struct Counters { uint32_t v[C_COUNT]; };
+struct Counters { uint32_t v[C_COUNT]; uint32_t elided = 0; };   // elided: rays counted in v[C_RAYS] but not traced
 
 // Result of a closest-hit query, as ids (the payload of the winner is recomputed on demand).
 struct Hit { bool hit; float dist; uint32_t obj, tri; };
@@ -630,7 +631,12 @@ SRT_DEV Spec path_sample(const DScene& S, uint32_t x, uint32_t y, Rng& rng, Coun
     const Scatter s1 = scatter(m, out_dir, rng);
     const V3 world_in = frame_to_world(fr, s1.dir);
     const Ray r1 = make_ray(sf.position, world_in, kEps, FLT_MAX);
-    Spec direct = emitted_along<COUNT>(S, r1, cnt);
+    // S.elide (no delta / environment light, every continuous BSDF Lambertian): the term of this ray is added and subtracted
+    // again below, +0 for any finite value and NaN together with the MIS term otherwise - the ray is counted, not traced
+    const bool dead = S.elide != 0u && !discrete;
+    Spec direct = spec(0, 0, 0);
+    if (dead) { cnt.v[C_RAYS]++; cnt.elided++; }
+    else direct = emitted_along<COUNT>(S, r1, cnt);
     float pdf = 0.0f;
     if (discrete) {
       direct = direct * s1.atten;

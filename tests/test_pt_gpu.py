@@ -477,11 +477,21 @@ def test_dead_ray_elision_is_bit_identical(srt, name, use_bvh, wh, spp, depth, e
     rays_full = pt.ray_count(reset=True)[0]
     assert bits_equal(full, want) and pt.rays_elided(reset=True) == 0
     pt.set_elision(True)
-    img = pt.render_epoch(5, 9, spp)
-    rays, elided = pt.ray_count(reset=True)[0], pt.rays_elided(reset=True)
-    assert bits_equal(img, want), "elision changed the image"
-    assert rays == rays_full, "the reference-equivalent ray count must not depend on elision"
-    assert (0 < elided < rays) if expect_elided else elided == 0
+    counts = []
+    for mode in (2, 4, 1):                                # wave kernel (two-ray batches), lane per sample, lane per pixel
+        pt.set_kernel(mode)
+        img = pt.render_epoch(5, 9, spp)
+        rays, elided = pt.ray_count(reset=True)[0], pt.rays_elided(reset=True)
+        assert bits_equal(img, want), f"elision changed the image (mode {mode})"
+        assert rays == rays_full, "the reference-equivalent ray count must not depend on elision"
+        assert (0 < elided < rays) if expect_elided else elided == 0
+        counts.append(elided)
+    assert counts[0] == counts[1] == counts[2]            # the same rays are dead for every kernel
+    if "delta" not in name and "env" not in name:         # (the flattened walk has no point_lighting: it refuses those scenes)
+        pt.set_kernel(5)                                  # flattened walk: the switch is ignored
+        assert bits_equal(pt.render_epoch(5, 9, spp), want) and pt.rays_elided(reset=True) == 0
+    pt.ray_count(reset=True)
+    pt.set_kernel(2)
     pt.set_tiling(16, 8, 2, 3)          # sharded + elided
     part = np.full((h, w, 3), -1.0, np.float32)
     pt.render_epoch(5, 9, spp, out=part)

@@ -32,6 +32,17 @@ for mode in modes:
     rays, cams = pt.ray_count()
     imgs.append(img)
     print(f"mode {mode}: {dt*1e3:.1f} ms, {rays/dt/1e6:.0f} Mrays/s, {rays/cams:.2f} rays/sample")
+if os.environ.get("SRT_ELIDE"):
+    pt.set_elision(True)
+    for mode in modes:
+        pt.set_kernel(mode)
+        pt.render_epoch(0, 0, 1)
+        pt.ray_count(reset=True); pt.rays_elided(reset=True)
+        t = time.perf_counter(); img = pt.render_epoch(0, 0, spp); dt = time.perf_counter() - t
+        rays, cams = pt.ray_count(); el = pt.rays_elided()
+        imgs.append(img)
+        print(f"mode {mode} + elision: {dt*1e3:.1f} ms, {rays/dt/1e6:.0f} reference-equivalent Mrays/s, {(rays-el)/dt/1e6:.0f} traced, {el/rays:.3f} elided")
+    pt.set_elision(False)
 print("modes bit-identical:", all(np.array_equal(imgs[0].view(np.uint32), i.view(np.uint32)) for i in imgs[1:]))
 rng = np.random.default_rng(0); n = 20000
 xs, ys, ss = rng.integers(0, size, n), rng.integers(0, size, n), rng.integers(0, spp, n)
