@@ -40,17 +40,21 @@ def main():
     shutil.copy(write, f"profiles/{tag}_pmc_write_size_l2.csv")
     f, nf = per_launch(fetch, "pt_wave_kernel")
     w, nw = per_launch(write, "pt_wave_kernel")
-    avg_ns = None
+    avg_ns = avg_ns_two = None      # the all-rays build (NR = 3, the bench's `value`) and the two-ray build of the elision pass
     with open(stats, newline="") as fh:
         for row in csv.DictReader(fh):
             if "pt_wave_kernel" in row["Name"]:
-                avg_ns = float(row["AverageNs"])
+                if ", 2>" in row["Name"]:
+                    avg_ns_two = float(row["AverageNs"])
+                else:
+                    avg_ns = float(row["AverageNs"])
     fetch_b = f["FETCH_SIZE"] * 1024 * 2
     write_b = w["WRITE_SIZE"] * 1024
     doc = {
         "workload": {"scene": "cbox", "size": 1024, "spp_per_step": 64, "n_gpus": 1},
         "kernel": "pt_wave_kernel",
         "kernel_avg_ns": avg_ns,
+        "two_ray_kernel_avg_ns": avg_ns_two,
         "launches_sampled": {"fetch": nf, "write": nw},
         "FETCH_SIZE_KB_per_launch": f["FETCH_SIZE"],
         "WRITE_SIZE_KB_per_launch": w["WRITE_SIZE"],
@@ -60,7 +64,7 @@ def main():
         "hbm_write_bytes_per_launch": write_b,
         "hbm_bytes_per_launch": fetch_b + write_b,
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes of "
-                  "`bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-raster`; FETCH_SIZE doubled per the gfx950 "
+                  "`bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-raster --no-overlap --no-elision`; FETCH_SIZE doubled per the gfx950 "
                   "note in MI355X_MICROARCH.md; WRITE_SIZE is uncalibrated for this kernel's dword-per-lane stores",
     }
     # optional: the SQ passes of tools/pmc_sq.sh <tag minus the round prefix> (gpurun_out/pmc_*/{a,b}) -> wave-instruction counts
