@@ -936,8 +936,9 @@ int srt_pt_trace_samples(srt_pt* pt, uint64_t seed, const uint32_t* xs, const ui
     if (xs[i] >= pt->w || ys[i] >= pt->h) return srt::fail(SRT_ERR_INVALID, "sample %zu: pixel (%u,%u) outside %ux%u", i, xs[i], ys[i], pt->w, pt->h);
   uint32_t *dx = nullptr, *dy = nullptr, *ds = nullptr, *dd = nullptr, *dr = nullptr;
   float* drgb = nullptr;
-  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dy, n * 4)); SRT_HIP(hipMalloc(&ds, n * 4));
-  SRT_HIP(hipMalloc(&dd, n * 4)); SRT_HIP(hipMalloc(&dr, n * 4)); SRT_HIP(hipMalloc(&drgb, n * 12));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dy, n * 4)); SRT_HIP(tmp.alloc(&ds, n * 4));
+  SRT_HIP(tmp.alloc(&dd, n * 4)); SRT_HIP(tmp.alloc(&dr, n * 4)); SRT_HIP(tmp.alloc(&drgb, n * 12));
   SRT_HIP(hipMemcpyAsync(dx, xs, n * 4, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(dy, ys, n * 4, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(ds, ss, n * 4, hipMemcpyHostToDevice, pt->stream));
@@ -950,7 +951,6 @@ int srt_pt_trace_samples(srt_pt* pt, uint64_t seed, const uint32_t* xs, const ui
   if (rays_out) SRT_HIP(hipMemcpyAsync(rays_out, dr, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipMemcpyAsync(pt->last_counters, pt->d_totals, sizeof pt->last_counters, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(ds); (void)hipFree(dd); (void)hipFree(dr); (void)hipFree(drgb);
   return SRT_OK;
 }
 
@@ -961,7 +961,8 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
   if (n == 0) return SRT_OK;
   if (!origins || !dirs || !bounds || !out9) return srt::fail(SRT_ERR_INVALID, "srt_pt_hit: NULL argument");
   float *dorg = nullptr, *ddir = nullptr, *db = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&dorg, n * 12)); SRT_HIP(hipMalloc(&ddir, n * 12)); SRT_HIP(hipMalloc(&db, n * 8)); SRT_HIP(hipMalloc(&dout, n * 36));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dorg, n * 12)); SRT_HIP(tmp.alloc(&ddir, n * 12)); SRT_HIP(tmp.alloc(&db, n * 8)); SRT_HIP(tmp.alloc(&dout, n * 36));
   SRT_HIP(hipMemcpyAsync(dorg, origins, n * 12, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(ddir, dirs, n * 12, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(db, bounds, n * 8, hipMemcpyHostToDevice, pt->stream));
@@ -975,7 +976,6 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out9, dout, n * 36, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dorg); (void)hipFree(ddir); (void)hipFree(db); (void)hipFree(dout);
   return SRT_OK;
 }
 
@@ -1013,14 +1013,14 @@ int srt_pt_math_cos_sin(srt_pt* pt, const float* x, size_t n, float* cos_out, fl
   if (st != SRT_OK) return st;
   if (n == 0) return SRT_OK;
   float *dx = nullptr, *dc = nullptr, *dsn = nullptr;
-  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dc, n * 4)); SRT_HIP(hipMalloc(&dsn, n * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dc, n * 4)); SRT_HIP(tmp.alloc(&dsn, n * 4));
   SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
   pt_math_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, n, dc, dsn);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(cos_out, dc, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipMemcpyAsync(sin_out, dsn, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dx); (void)hipFree(dc); (void)hipFree(dsn);
   return SRT_OK;
 }
 
@@ -1030,13 +1030,13 @@ int srt_pt_math_acos(srt_pt* pt, const float* x, size_t n, float* out) {
   if (!x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_acos: NULL argument");
   if (!n) return SRT_OK;
   float *dx = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dout, n * 4));
   SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
   pt_acos_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, n, dout);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dx); (void)hipFree(dout);
   return SRT_OK;
 }
 
@@ -1046,14 +1046,14 @@ int srt_pt_math_atan2(srt_pt* pt, const float* y, const float* x, size_t n, floa
   if (!y || !x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_atan2: NULL argument");
   if (!n) return SRT_OK;
   float *dy = nullptr, *dx = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&dy, n * 4)); SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dy, n * 4)); SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dout, n * 4));
   SRT_HIP(hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
   pt_atan2_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dy, dx, n, dout);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dout);
   return SRT_OK;
 }
 
@@ -1079,15 +1079,15 @@ int srt_pt_tonemap(srt_pt* pt, const float* rgb, uint32_t width, uint32_t height
   const size_t px = (size_t)width * height;
   if (!px) return SRT_OK;
   float* d_in = nullptr; uint8_t* d_out = nullptr;
-  SRT_HIP(hipMalloc(&d_in, px * 12));
-  if (hipMalloc(&d_out, px * 4) != hipSuccess) { (void)hipFree(d_in); return srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: out of device memory"); }
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&d_in, px * 12));
+  SRT_HIP(tmp.alloc(&d_out, px * 4));
   st = SRT_OK;
   if (hipMemcpyAsync(d_in, rgb, px * 12, hipMemcpyHostToDevice, pt->stream) != hipSuccess) st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: upload failed");
   if (st == SRT_OK) st = srt_pt_tonemap_device(pt, nullptr, d_in, width, height, exposure, d_out);
   if (st == SRT_OK && (hipMemcpyAsync(rgba_out, d_out, px * 4, hipMemcpyDeviceToHost, pt->stream) != hipSuccess ||
                        hipStreamSynchronize(pt->stream) != hipSuccess))
     st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: download failed");
-  (void)hipFree(d_in); (void)hipFree(d_out);
   return st;
 }
 
@@ -1097,13 +1097,13 @@ int srt_pt_math_exp(srt_pt* pt, const float* x, size_t n, float* out) {
   if (!x || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_exp: NULL argument");
   if (!n) return SRT_OK;
   float *dx = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dout, n * 4));
   SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
   pt_exp_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, n, dout);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dx); (void)hipFree(dout);
   return SRT_OK;
 }
 
@@ -1113,14 +1113,14 @@ int srt_pt_math_pow(srt_pt* pt, const float* x, const float* y, size_t n, float*
   if (!x || !y || !out) return srt::fail(SRT_ERR_INVALID, "srt_pt_math_pow: NULL argument");
   if (!n) return SRT_OK;
   float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&dx, n * 4)); SRT_HIP(hipMalloc(&dy, n * 4)); SRT_HIP(hipMalloc(&dout, n * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dx, n * 4)); SRT_HIP(tmp.alloc(&dy, n * 4)); SRT_HIP(tmp.alloc(&dout, n * 4));
   SRT_HIP(hipMemcpyAsync(dx, x, n * 4, hipMemcpyHostToDevice, pt->stream));
   SRT_HIP(hipMemcpyAsync(dy, y, n * 4, hipMemcpyHostToDevice, pt->stream));
   pt_pow_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pt->stream>>>(dx, dy, n, dout);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
   return SRT_OK;
 }
 
@@ -1131,13 +1131,13 @@ int srt_pt_math_div_sqrt(srt_pt* pt, const float* in, size_t lanes, int shared_c
   if (!lanes) return SRT_OK;
   const size_t n3 = lanes * 3;
   float *din = nullptr, *dout = nullptr;
-  SRT_HIP(hipMalloc(&din, 5 * n3 * 4)); SRT_HIP(hipMalloc(&dout, 4 * n3 * 4));
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&din, 5 * n3 * 4)); SRT_HIP(tmp.alloc(&dout, 4 * n3 * 4));
   SRT_HIP(hipMemcpyAsync(din, in, 5 * n3 * 4, hipMemcpyHostToDevice, pt->stream));
   pt_div_sqrt_kernel<<<dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, pt->stream>>>(din, lanes, shared_c2, dout);
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out, dout, 4 * n3 * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  (void)hipFree(din); (void)hipFree(dout);
   return SRT_OK;
 }
 

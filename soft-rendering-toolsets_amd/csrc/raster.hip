@@ -471,7 +471,7 @@ int upload_stream(srt_raster* r) {
   if (n > r->d_cap) {
     if (r->d_prims) SRT_HIP(hipFree(r->d_prims));
     if (r->d_bbox) SRT_HIP(hipFree(r->d_bbox));
-    r->d_prims = nullptr; r->d_bbox = nullptr;
+    r->d_prims = nullptr; r->d_bbox = nullptr; r->d_cap = 0;
     size_t cap = n + n / 2 + 64;
     SRT_HIP(hipMalloc(&r->d_prims, cap * sizeof(srt_prim)));
     SRT_HIP(hipMalloc(&r->d_bbox, cap * sizeof(int4)));
@@ -555,13 +555,13 @@ int upload_stream(srt_raster* r) {
   if (!aux.empty()) {
     if (aux.size() > r->aux_cap) {
       if (r->d_aux) SRT_HIP(hipFree(r->d_aux));
-      r->d_aux = nullptr;
+      r->d_aux = nullptr; r->aux_cap = 0;      // a failed allocation below must not leave a capacity behind
       SRT_HIP(hipMalloc(&r->d_aux, aux.size() * sizeof(ImageAux)));
       r->aux_cap = aux.size();
     }
     if (tabs.size() > r->tabs_cap) {
       if (r->d_tabs) SRT_HIP(hipFree(r->d_tabs));
-      r->d_tabs = nullptr;
+      r->d_tabs = nullptr; r->tabs_cap = 0;      // a failed allocation below must not leave a capacity behind
       SRT_HIP(hipMalloc(&r->d_tabs, tabs.size() * sizeof(float)));
       r->tabs_cap = tabs.size();
     }
@@ -571,7 +571,7 @@ int upload_stream(srt_raster* r) {
       const size_t nb = r->texel_blob.size() ? r->texel_blob.size() : 4;
       if (nb > r->texels_cap) {
         if (r->d_texels) SRT_HIP(hipFree(r->d_texels));
-        r->d_texels = nullptr;
+        r->d_texels = nullptr; r->texels_cap = 0;      // a failed allocation below must not leave a capacity behind
         SRT_HIP(hipMalloc(&r->d_texels, nb));
         r->texels_cap = nb;
       }
@@ -599,13 +599,13 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
     const size_t nb = (size_t)P.coarse_x * P.coarse_y;
     if (r->counts_cap < nb) {
       if (r->d_counts) SRT_HIP(hipFree(r->d_counts));
-      r->d_counts = nullptr;
+      r->d_counts = nullptr; r->counts_cap = 0;      // a failed allocation below must not leave a capacity behind
       SRT_HIP(hipMalloc(&r->d_counts, nb * sizeof(uint32_t)));
       r->counts_cap = nb;
     }
     if (r->lists_cap < nb * P.list_stride) {
       if (r->d_lists) SRT_HIP(hipFree(r->d_lists));
-      r->d_lists = nullptr;
+      r->d_lists = nullptr; r->lists_cap = 0;      // a failed allocation below must not leave a capacity behind
       SRT_HIP(hipMalloc(&r->d_lists, nb * P.list_stride * sizeof(uint32_t)));
       r->lists_cap = nb * P.list_stride;
     }
@@ -738,7 +738,7 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   P.tiles_y = (height + P.tile_py - 1) / P.tile_py;
   if (realloc_px) {
     if (r->d_rgba) SRT_HIP(hipFree(r->d_rgba));
-    r->d_rgba = nullptr;
+    r->d_rgba = nullptr; r->have_target = false;   // until the allocation below has succeeded
     SRT_HIP(hipMalloc(&r->d_rgba, (size_t)width * height * 4));
   }
   if (r->d_samples) { SRT_HIP(hipFree(r->d_samples)); r->d_samples = nullptr; }

@@ -25,4 +25,27 @@ int fail(int status, const char* fmt, ...);
                        __LINE__);                                                              \
   } while (0)
 
+// Device buffers that live for one C-ABI call: freed when the call returns, on the error paths of SRT_HIP too.
+#ifdef __cplusplus
+#include <vector>
+namespace srt {
+class DeviceScratch {
+ public:
+  DeviceScratch() = default;
+  DeviceScratch(const DeviceScratch&) = delete;
+  DeviceScratch& operator=(const DeviceScratch&) = delete;
+  ~DeviceScratch() { for (void* p : owned_) (void)hipFree(p); }
+  template <typename T>
+  hipError_t alloc(T** out, size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) { owned_.push_back(p); *out = static_cast<T*>(p); }
+    return e;
+  }
+ private:
+  std::vector<void*> owned_;
+};
+}  // namespace srt
+#endif
+
 #endif
