@@ -324,8 +324,13 @@ int need_ready(srt_pt* pt, const char* what) {
 bool elision_provable(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   if (!pt->elide || !F.delta_lights.empty() || pt->env_type != 0) return false;
-  for (const Material& m : F.materials)
+  for (const Material& m : F.materials) {
     if (m.type == 3u && !(0.2126f * m.a[0] + 0.7152f * m.a[1] + 0.0722f * m.a[2] > 0.0f)) return false;
+    // the dead term is emission x albedo x cos x 1/pdf with 1/pdf <= pi / cos(1): finite as long as the factors are moderate
+    if (m.type == 0u || m.type == 3u)
+      for (int i = 0; i < 3; i++)
+        if (!(fabsf(m.a[i]) <= 1e15f)) return false;
+  }
   return true;
 }
 
