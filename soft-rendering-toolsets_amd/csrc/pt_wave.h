@@ -148,13 +148,26 @@ SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, 
   return hit;
 }
 
+constexpr uint32_t kRetMiss = 0xFFFFFFFFu;
+constexpr uint32_t kRetMissEnv = 0xFFFFFFFEu;   // miss, and the environment light is visible along the (camera) ray
+SRT_DEV uint32_t pack_ret(const Hit& h) { return h.hit ? ((h.obj << 27) | h.tri) : kRetMiss; }
+SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
+  Hit h;
+  h.hit = id != kRetMiss;
+  h.dist = h.hit ? dist : 0.0f;
+  h.obj = h.hit ? (id >> 27) : 0;
+  h.tri = h.hit ? (id & 0x07FFFFFFu) : 0;
+  return h;
+}
+SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
+
 // Object::hit of object slot k for the three rays of a batch (shared origin), wave-uniformly: hit flag, the
 // world distance Trace::transform recomputes, and the winning triangle (global index).
 // HAS_BLAS = false compiles the per-lane BVH<Triangle> walk out (the host picks that build when every mesh is a
 // single leaf, e.g. the Cornell box): the walk's registers would otherwise halve the occupancy of the common path.
 template <bool HAS_BLAS, int NR>
 SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
-                          Counters& cnt, bool* hit, float* dist, uint32_t* tri) {
+                          Counters& cnt, bool* hit, float* dist, uint32_t* tri, const bool* need, uint32_t* cidx) {
   const Object& o = S.objects[k];
   const bool xf = o.has_trans != 0;
   V3 oorg = org;
@@ -198,16 +211,59 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
     sqrtN<NR>(n2, miss, nr);
 #pragma unroll
     for (int r = 0; r < NR; r++) dist[r] = fabsf(nr[r]);
-  } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) {   // a real BVH<Triangle>: per-lane walk
+  } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) {
+    // A real BVH<Triangle>: a per-lane walk, the expensive leaf.  Only the rays whose traversal can reach this object
+    // (need[], from the caller) are walked, and they are compacted over the wave first: the (lane, slot) pairs get
+    // consecutive item numbers (ballot prefix), each lane then walks item `round * 64 + lane` - fetched from its owner
+    // with ds_bpermute - and the owners collect the results the same way.  A batch of NR x 64 slots of which a third
+    // needs the mesh costs one walk instead of NR.
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t pos_[NR], total = 0;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      Ray ray;
-      ray.o = oorg; ray.d = od[r]; ray.b0 = ob0[r]; ray.b1 = ob1[r];
-      const Hit mh = mesh_hit<false>(S, o, ray, cnt);
-      hit[r] = mh.hit; dist[r] = mh.dist; tri[r] = mh.tri;
-      pos[r] = v3(0, 0, 0);
-      if (mh.hit && xf) { const TriHit th = tri_hit(S.tris[mh.tri], ray); pos[r] = ray_at(ray, th.t); }
+      const unsigned long long m = __ballot(need[r]);
+      pos_[r] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      total += (uint32_t)__popcll(m);
+      hit[r] = false; dist[r] = 0.0f; tri[r] = 0u;
     }
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      if (need[r]) cidx[pos_[r]] = (uint32_t)lane | ((uint32_t)r << 6);
+    for (uint32_t base = 0; base < total; base += 64u) {
+      const uint32_t item = base + (uint32_t)lane;
+      const bool valid = item < total;
+      const uint32_t code = valid ? cidx[item] : (uint32_t)lane;
+      const int src = (int)(code & 63u), rr = (int)(code >> 6);
+      Ray ray;
+      ray.o = v3(__shfl(oorg.x, src), __shfl(oorg.y, src), __shfl(oorg.z, src));
+      ray.d = v3(__shfl(od[0].x, src), __shfl(od[0].y, src), __shfl(od[0].z, src));
+      ray.b0 = __shfl(ob0[0], src); ray.b1 = __shfl(ob1[0], src);
+#pragma unroll
+      for (int r = 1; r < NR; r++) {                     // every lane reads the NR candidates of lane `src`, keeps its slot's
+        const float x = __shfl(od[r].x, src), y = __shfl(od[r].y, src), z = __shfl(od[r].z, src);
+        const float c0 = __shfl(ob0[r], src), c1 = __shfl(ob1[r], src);
+        if (rr == r) { ray.d = v3(x, y, z); ray.b0 = c0; ray.b1 = c1; }
+      }
+      Hit mh = no_hit();
+      float wd = 0.0f;
+      if (valid) {
+        mh = mesh_hit<false>(S, o, ray, cnt);
+        wd = mh.dist;
+        if (mh.hit && xf) {                              // Trace::transform: distance = |T*position - T*origin|
+          const TriHit th = tri_hit(S.tris[mh.tri], ray);
+          wd = norm(mat_point(o.trans, ray_at(ray, th.t)) - mat_point(o.trans, ray.o));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NR; r++) {                     // results back to the owners
+        const int from = (int)((pos_[r] - base) & 63u);
+        const int h_ = __shfl(mh.hit ? 1 : 0, from);
+        const float d_ = __shfl(wd, from);
+        const uint32_t t_ = (uint32_t)__shfl((int)mh.tri, from);
+        if (need[r] && pos_[r] >= base && pos_[r] < base + 64u) { hit[r] = h_ != 0; dist[r] = d_; tri[r] = t_; }
+      }
+    }
+    return;                                              // world distances are final
   } else {                                            // one leaf of <= 4 triangles, or List<Triangle>: ordered fold
     bool bh[NR];
     float bd[NR], bt[NR];
@@ -251,18 +307,6 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
   }
 }
 
-constexpr uint32_t kRetMiss = 0xFFFFFFFFu;
-constexpr uint32_t kRetMissEnv = 0xFFFFFFFEu;   // miss, and the environment light is visible along the (camera) ray
-SRT_DEV uint32_t pack_ret(const Hit& h) { return h.hit ? ((h.obj << 27) | h.tri) : kRetMiss; }
-SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
-  Hit h;
-  h.hit = id != kRetMiss;
-  h.dist = h.hit ? dist : 0.0f;
-  h.obj = h.hit ? (id >> 27) : 0;
-  h.tri = h.hit ? (id & 0x07FFFFFFu) : 0;
-  return h;
-}
-SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
 
 // Scene arrays are passed as separate `const T* __restrict__` kernel arguments (not inside DScene): only then can
 // the compiler prove that the stores to records / sample_out do not clobber them and turn the wave-uniform
@@ -284,7 +328,10 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC2
 #define SRT_WAVE_OCC2 5
 #endif
-__global__ __launch_bounds__(256, NR == 2 ? SRT_WAVE_OCC2 : SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+#ifndef SRT_WAVE_OCC2T
+#define SRT_WAVE_OCC2T 4
+#endif
+__global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WAVE_OCC2) : SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
@@ -298,7 +345,10 @@ __global__ __launch_bounds__(256, NR == 2 ? SRT_WAVE_OCC2 : SRT_WAVE_OCC) void p
   WaveParams P = P_in;
   P.records = a_records; P.sample_out = a_samples;
   extern __shared__ float lds_f[];
+  // item table of the compacted per-lane walks (object_testN): one dword per batch slot of the wave
+  __shared__ uint32_t s_cidx[TRAV == 1 ? 4 * NR * 64 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* const cidx = s_cidx + (TRAV == 1 ? wave * NR * 64 : 0);
   const uint32_t nobj = S.nobjects;
   const uint32_t Q = S.use_bvh ? S.wave_q : 0u;
   unsigned long long stamp_acc[ST_COUNT_] = {0, 0, 0, 0, 0, 0, 0};
@@ -451,6 +501,12 @@ __global__ __launch_bounds__(256, NR == 2 ? SRT_WAVE_OCC2 : SRT_WAVE_OCC) void p
       for (int r = 0; r < NR; r++) rb1[r] = shb ? sb1[r] : cb1;
     }
     Hit res[NR];
+    bool act[NR];                                        // slots of this lane's batch that carry a ray
+#pragma unroll
+    for (int r = 0; r < NR; r++) act[r] = alive;
+    if (shb) { if (NR > 1) act[1] = alive && sa1; if (NR > 2) act[NR - 1] = alive && sa2; }
+    else if (burst) { if (NR > 1) act[1] = alive && actA; if (NR > 2) act[NR - 1] = alive && actB; }
+    else if (NR == 3) { act[0] = alive && actA; act[1] = alive && actB; }
     bool batch_ready = alive;                            // the lane's batch has been traced completely
     if constexpr (TRAV == 2) {
       // general scenes: one flattened per-lane walk over both tree levels for the slots that carry a ray
@@ -469,7 +525,7 @@ __global__ __launch_bounds__(256, NR == 2 ? SRT_WAVE_OCC2 : SRT_WAVE_OCC) void p
       for (int r = 0; r < NR; r++) res[r] = no_hit();
       for (uint32_t k = 0; k < nobj; k++) {
         bool h[NR]; float dd[NR]; uint32_t tt[NR];
-        object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+        object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, act, cidx);
 #pragma unroll
         for (int r = 0; r < NR; r++) fold(res[r], h[r], dd[r], k, tt[r]);
       }
@@ -513,34 +569,48 @@ __global__ __launch_bounds__(256, NR == 2 ? SRT_WAVE_OCC2 : SRT_WAVE_OCC) void p
       for (int q = (int)Q - 1; q >= 0; q--) {
         const WaveInterior& W = S.wave_tlas[q];
         Hit L[NR], R[NR];
-        if (W.l_ref >= 0) {
+        // A leaf child that holds a mesh with a real BVH<Triangle> is evaluated after its sibling and only for the rays
+        // whose traversal can reach it: find_closest_hit visits the nearer child, and the other one iff
+        // `cur_far_t.x < ret.distance || (!ret.hit && hitboth)` (student/bvh.inl:216) - whether node q itself is reached is
+        // not known yet (bottom-up), so that part is assumed.  Rays that do not need it get "no hit", which the
+        // combination below never selects.
+        auto lazy_leaf = [&](int32_t ref, uint32_t n) {
+          if (TRAV != 1 || ref >= 0 || n != 1u) return false;
+          const Object& ob = S.objects[(uint32_t)~ref];
+          return ob.kind == OBJ_MESH && ob.use_bvh != 0u && ob.nrec > 0u;
+        };
+        auto eval_child = [&](int32_t ref, uint32_t n, Hit* out, const bool* need) {
+          if (ref >= 0) {
 #pragma unroll
-          for (int r = 0; r < NR; r++) L[r] = unpack_ret(SLOT(W.l_ref, r, 0), __float_as_uint(SLOT(W.l_ref, r, 1)));
-        } else {
+            for (int r = 0; r < NR; r++) out[r] = unpack_ret(SLOT(ref, r, 0), __float_as_uint(SLOT(ref, r, 1)));
+          } else {
 #pragma unroll
-          for (int r = 0; r < NR; r++) L[r] = no_hit();
-          const uint32_t first = (uint32_t)~W.l_ref;
-          for (uint32_t k = first; k < first + W.l_cnt; k++) {
-            bool h[NR]; float dd[NR]; uint32_t tt[NR];
-            object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
+            for (int r = 0; r < NR; r++) out[r] = no_hit();
+            const uint32_t first = (uint32_t)~ref;
+            for (uint32_t k = first; k < first + n; k++) {
+              bool h[NR]; float dd[NR]; uint32_t tt[NR];
+              object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, need, cidx);
 #pragma unroll
-            for (int r = 0; r < NR; r++) fold(L[r], h[r], dd[r], k, tt[r]);
+              for (int r = 0; r < NR; r++) fold(out[r], h[r], dd[r], k, tt[r]);
+            }
           }
-        }
-        if (W.r_ref >= 0) {
+        };
+        auto need_of = [&](bool is_left, const Hit* other, bool other_known, bool* need) {
 #pragma unroll
-          for (int r = 0; r < NR; r++) R[r] = unpack_ret(SLOT(W.r_ref, r, 0), __float_as_uint(SLOT(W.r_ref, r, 1)));
-        } else {
-#pragma unroll
-          for (int r = 0; r < NR; r++) R[r] = no_hit();
-          const uint32_t first = (uint32_t)~W.r_ref;
-          for (uint32_t k = first; k < first + W.r_cnt; k++) {
-            bool h[NR]; float dd[NR]; uint32_t tt[NR];
-            object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt);
-#pragma unroll
-            for (int r = 0; r < NR; r++) fold(R[r], h[r], dd[r], k, tt[r]);
+          for (int r = 0; r < NR; r++) {
+            const uint32_t f = (uint32_t)(fl[r] >> (4 * q)) & 15u;
+            const bool nearer = ((f & 4u) != 0) == is_left;
+            const float farx = (q != 0) ? SLOT(q, r, 0) : farx0[r];
+            const bool second = !other_known || farx < other[r].dist || (!other[r].hit && (f & 8u));
+            need[r] = act[r] && (f & 3u) != 0 && (nearer || second);
           }
-        }
+        };
+        const bool lazy_l = lazy_leaf(W.l_ref, W.l_cnt), lazy_r = lazy_leaf(W.r_ref, W.r_cnt);
+        bool need[NR];
+        if (!lazy_l) eval_child(W.l_ref, W.l_cnt, L, act);
+        if (!lazy_r) eval_child(W.r_ref, W.r_cnt, R, act);
+        if (lazy_l) { need_of(true, R, !lazy_r, need); eval_child(W.l_ref, W.l_cnt, L, need); }
+        if (lazy_r) { need_of(false, L, true, need); eval_child(W.r_ref, W.r_cnt, R, need); }
         SECTION_END(ST_LEAVES)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
