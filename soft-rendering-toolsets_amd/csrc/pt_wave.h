@@ -37,6 +37,7 @@
 #ifndef SRT_PT_WAVE_H
 #define SRT_PT_WAVE_H
 
+
 #include "pt_trace.h"
 #include "pt_flat.h"
 
@@ -605,12 +606,36 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
             need[r] = act[r] && (f & 3u) != 0 && (nearer || second);
           }
         };
+        if constexpr (TRAV != 1) {                       // no per-lane walks: both children straight, in order
+          eval_child(W.l_ref, W.l_cnt, L, act);
+          eval_child(W.r_ref, W.r_cnt, R, act);
+        } else {
         const bool lazy_l = lazy_leaf(W.l_ref, W.l_cnt), lazy_r = lazy_leaf(W.r_ref, W.r_cnt);
-        bool need[NR];
-        if (!lazy_l) eval_child(W.l_ref, W.l_cnt, L, act);
-        if (!lazy_r) eval_child(W.r_ref, W.r_cnt, R, act);
-        if (lazy_l) { need_of(true, R, !lazy_r, need); eval_child(W.l_ref, W.l_cnt, L, need); }
-        if (lazy_r) { need_of(false, L, true, need); eval_child(W.r_ref, W.r_cnt, R, need); }
+        const bool right_first = lazy_l && !lazy_r;      // the sibling of a lazy leaf goes first
+        Hit first_out[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) { first_out[r] = no_hit(); L[r] = no_hit(); R[r] = no_hit(); }
+        // one call site for both children (a loop that is not unrolled): the leaf tests are most of the kernel's code
+#pragma nounroll
+        for (int t = 0; t < 2; t++) {
+          const bool left = (t == 0) != right_first;
+          const int32_t ref = left ? W.l_ref : W.r_ref;
+          const uint32_t n = left ? W.l_cnt : W.r_cnt;
+          bool need[NR];
+          if (left ? lazy_l : lazy_r) need_of(left, first_out, t == 1, need);
+          else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) need[r] = act[r];
+          }
+          Hit out[NR];
+          eval_child(ref, n, out, need);
+#pragma unroll
+          for (int r = 0; r < NR; r++) {
+            if (t == 0) first_out[r] = out[r];
+            if (left) L[r] = out[r]; else R[r] = out[r];
+          }
+        }
+        }
         SECTION_END(ST_LEAVES)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
