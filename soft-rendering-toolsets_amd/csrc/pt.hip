@@ -397,8 +397,8 @@ int wave_trav(const srt_pt* pt) {
   if (m == 3) return (sweeps_fit && !lights) ? (blas ? 1 : 0) : -1;
   if (m == 5) return (flat_fits && !lights) ? 2 : -1;
   // auto: the sweeps whenever the scene has few enough objects.  Meshes with a real BVH<Triangle> are walked per lane
-  // inside the sweeps, only by the rays that can reach them and compacted over the wave (object_testN): 380 / 584 / 1208
-  // Mrays/s on the 131 k / 8 k / 512-triangle test scenes against 367 / 473 / 673 for the lane-per-sample kernel,
+  // inside the sweeps, only by the rays that can reach them and compacted over the wave (object_testN): 407 / 771 / 1458
+  // Mrays/s on the 131 k / 8 k / 512-triangle test scenes against 367 / 475 / 676 for the lane-per-sample kernel,
   // which remains the path for larger scenes (and is still ahead of the flattened walk there).
   if (sweeps_fit) return blas ? 1 : 0;
   return -1;

@@ -237,13 +237,92 @@ SRT_DEV Hit traverse_records(const DScene& S, const Object& o, const Ray& ray, f
   }
 }
 
+// The same walk for lanes that walk together (the compacted rounds of the wave kernel, pt_wave.h): "while-while" form.
+// The wave repeats interior steps while any lane stands at an interior record - lanes that have reached a leaf wait -,
+// then every lane that is still walking tests the triangles of its leaf; a single loop with `leaf ? tests : boxes`
+// would pay for both bodies on every step with about half of the lanes in each.  Same records, frames, visit rule and
+// results as traverse_records.
+template <int MAXD>
+SRT_DEV Hit traverse_records_together(const DScene& S, const Object& o, const Ray& ray, float tx, float ty) {
+  const WaveInterior* __restrict__ recs = S.blas_recs + o.rec_base;
+  const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  RecFrame stack[MAXD];
+  int sp = 0;
+  int32_t cur = 0;
+  bool done = false;
+  Hit ret;
+  ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+  // after a node has produced `ret`: pop finished frames; stop at one whose second child has to be visited (-> cur) or when
+  // the stack is empty (-> done, ret is the answer)
+  auto unwind = [&]() {
+    while (sp > 0) {
+      RecFrame& f = stack[sp - 1];
+      if (!(f.flags & 2u)) {
+        if (f.a < ret.dist || (!ret.hit && (f.flags & 1u))) {
+          cur = f.second; tx = f.a; ty = f.b;
+          f.flags |= 2u | (ret.hit ? 4u : 0u);
+          f.a = ret.dist; f.b = __uint_as_float(ret.tri);
+          return;
+        }
+        sp--;
+      } else {
+        if (left_wins((f.flags & 4u) != 0, f.a, ret.hit, ret.dist)) {
+          ret.hit = true; ret.dist = f.a; ret.obj = 0; ret.tri = __float_as_uint(f.b);
+        } else if (!ret.hit) {
+          ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+        }
+        sp--;
+      }
+    }
+    done = true;
+  };
+  for (;;) {
+    while (__ballot(!done && cur >= 0) != 0ull) {      // interior steps, together
+      if (!done && cur >= 0) {
+        const WaveInterior W = recs[cur];
+        float t1x = tx, t1y = ty, t2x = tx, t2y = ty;
+        const bool hl = box_hit_rec(W.boxl, ray.o, inv, t1x, t1y);
+        const bool hr = box_hit_rec(W.boxr, ray.o, inv, t2x, t2y);
+        if (hl || hr) {
+          const bool hb = hl && hr;
+          const bool cl = hb ? (t1x < t2x) : hl;
+          RecFrame& f = stack[sp++];
+          f.second = cl ? W.r_ref : W.l_ref;
+          f.a = hb ? (cl ? t2x : t1x) : ray.b0;
+          f.b = hb ? (cl ? t2y : t1y) : ray.b1;
+          f.flags = hb ? 1u : 0u;
+          cur = cl ? W.l_ref : W.r_ref;
+          tx = cl ? t1x : t2x;
+          ty = cl ? t1y : t2y;
+        } else {
+          ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+          unwind();
+        }
+      }
+    }
+    if (__ballot(!done) == 0ull) break;
+    if (!done) {                                        // every lane still walking stands at a leaf
+      const uint32_t packed = (uint32_t)~cur;
+      const uint32_t first = o.tri_base + (packed >> 3), n = packed & 7u;
+      ret.hit = false; ret.dist = 0.0f; ret.obj = 0; ret.tri = 0;
+      for (uint32_t i = 0; i < n; i++) {
+        const TriHit th = tri_hit(S.tris[first + i], ray);
+        fold(ret, th.hit, th.dist, 0, first + i);
+      }
+      unwind();
+    }
+  }
+  return ret;
+}
+
 // Closest triangle of one mesh in OBJECT space: Tri_Mesh::hit -> BVH<Triangle>::hit / List<Triangle>::hit.
 // Returns ids in Hit (tri = global triangle index).
-template <bool COUNT>
+template <bool COUNT, bool TOGETHER = false>
 SRT_DEV Hit mesh_hit(const DScene& S, const Object& o, const Ray& oray, Counters& cnt) {
   Hit best; best.hit = false; best.dist = 0.0f; best.obj = 0; best.tri = 0;
   if (o.use_bvh && o.nrec > 0) {
     const float dn = norm(oray.d);
+    if (TOGETHER && !COUNT) return traverse_records_together<kMaxBlasDepth>(S, o, oray, oray.b0 / dn, oray.b1 / dn);
     return traverse_records<kMaxBlasDepth, COUNT>(S, o, oray, oray.b0 / dn, oray.b1 / dn, cnt);  // times = dist_bounds / dir.norm()
   }
   if (o.use_bvh) {

@@ -248,7 +248,7 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       Hit mh = no_hit();
       float wd = 0.0f;
       if (valid) {
-        mh = mesh_hit<false>(S, o, ray, cnt);
+        mh = mesh_hit<false, true>(S, o, ray, cnt);      // the lanes of a round walk together (while-while form)
         wd = mh.dist;
         if (mh.hit && xf) {                              // Trace::transform: distance = |T*position - T*origin|
           const TriHit th = tri_hit(S.tris[mh.tri], ray);
