@@ -409,4 +409,21 @@ def random_pt_scene(seed):
     objs.insert(int(rng.integers(0, len(objs) + 1)), light)
     scene = {"name": f"random{seed}", "materials": mats, "objects": objs, "camera": dict(base["camera"])}
     w, h = int(rng.integers(20, 44)), int(rng.integers(16, 36))
-    return scene, w, h, int(rng.integers(1, 9)), bool(rng.random() < 0.85), int(rng.integers(2, 7))
+    out = (scene, w, h, int(rng.integers(1, 9)), bool(rng.random() < 0.85), int(rng.integers(2, 7)))
+    # seeds >= 100000 also draw delta lights (point / spot / directional, Pathtracer::point_lighting) and uniform environment
+    # lights; drawn last so that the scenes of the smaller seeds stay what they were
+    if seed >= 100000:
+        lights = []
+        for _ in range(int(rng.integers(0, 6)) if rng.random() < 0.6 else 0):
+            kind = int(rng.integers(0, 3))
+            L = {"type": kind, "radiance": rng.uniform(0.1, 2.5, 3).astype(np.float32),
+                 "T": sc._colmajor(pose(1.0, rng.uniform([-0.4, 0.2, -0.4], [0.4, 0.95, 0.4]), 0.6).reshape(-1))}
+            if kind == 2:
+                a = float(rng.uniform(10.0, 60.0))
+                L["angle_bounds"] = np.array([a, a + float(rng.uniform(5.0, 50.0))], np.float32)
+            lights.append(L)
+        if lights:
+            scene["lights"] = lights
+        if rng.random() < 0.3:
+            scene["env"] = {"type": int(rng.integers(1, 3)), "radiance": rng.uniform(0.1, 1.2, 3).astype(np.float32)}
+    return out
