@@ -389,7 +389,6 @@ int wave_trav(const srt_pt* pt) {
   if (m == 1 || m == 4) return -1;
   // delta lights (point_lighting's shadow batches) and environment lights: the sweeps' DL instantiation only
   const bool lights = !F.delta_lights.empty() || pt->env_type != 0;
-  if (pt->env_type == SRT_ENV_MAP) return -1;   // image environment maps: per-lane kernels only
   const bool blas = !F.blas_recs.empty();
   const bool sweeps_fit = F.objects.size() >= 1 && F.objects.size() <= kWaveMaxObjects && F.tris.size() < (1u << 27);
   const bool flat_fits = flat_walk_fits(F);

@@ -699,10 +699,11 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
           if (S.env_type != 0u) {
             // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
             // whether evaluate(dir) is the radiance or zero, the directions are gone when the parked samples are resolved
-            if (!res[0].hit && (S.env_type == 1u || d[0].y > 0.0f)) chit = kRetMissEnv;
+            // (an image map is evaluated when the sample is resolved, from its regenerated camera ray)
+            if (!res[0].hit && (S.env_type != 2u || d[0].y > 0.0f)) chit = kRetMissEnv;
 #pragma unroll
             for (int j = 0; j < NR - 1; j++)
-              if (!res[j + 1].hit && (S.env_type == 1u || d[j + 1].y > 0.0f)) pend[j] = kRetMissEnv;
+              if (!res[j + 1].hit && (S.env_type != 2u || d[j + 1].y > 0.0f)) pend[j] = kRetMissEnv;
           }
         }
       } else if constexpr (NR == 2) {
@@ -778,7 +779,18 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
         const Hit ch = unpack_ret(0.0f, miss_env ? kRetMiss : chit);
         bool terminal = !ch.hit;                         // student/pathtracer.cpp:174-218
         e = spec(0, 0, 0);
-        if (miss_env && level == 0) e = spec(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+        if (miss_env && level == 0) {
+          e = spec(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+          if (S.env_type == 3u) {                         // Env_Map::evaluate(ray.dir) of the sample's camera ray
+            Rng cr;
+            const uint32_t img_w = opq(S.w), img_h = opq(S.h);
+            cr.key(opq(P.seed), py * img_w + px, opq(P.sample_base) + s_cur);
+            const float jx = cr.unit() * 1.0f;
+            const float jy = cr.unit() * 1.0f;
+            const Ray cam = camera_ray(opq(S.cam), ((float)px + jx) / (float)img_w, ((float)py + jy) / (float)img_h);
+            e = env_map_evaluate(S, cam.d);
+          }
+        }
         if (!terminal) {
           mi = (uint32_t)S.objects[ch.obj].material;
           e = emissive_of(S.materials[mi]);

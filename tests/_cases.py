@@ -426,4 +426,7 @@ def random_pt_scene(seed):
             scene["lights"] = lights
         if rng.random() < 0.3:
             scene["env"] = {"type": int(rng.integers(1, 3)), "radiance": rng.uniform(0.1, 1.2, 3).astype(np.float32)}
+        elif seed >= 200000 and rng.random() < 0.5:          # image environment map (Env_Map)
+            eh, ew = int(rng.integers(2, 24)), int(rng.integers(2, 40))
+            scene["env"] = {"type": 3, "image": np.ascontiguousarray(rng.uniform(0.0, 1.5, (eh, ew, 3)), np.float32)}
     return out

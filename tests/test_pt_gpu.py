@@ -291,17 +291,19 @@ def test_emissive_sphere(srt):
 
 
 def test_environment_map(srt):
-    """Env_Map (image environment light) on the per-lane kernels against the oracle; the wave kernel refuses it."""
+    """Env_Map (image environment light): the per-lane kernels and the wave kernel (camera rays that leave the scene look the
+    map up from their regenerated direction when the sample is resolved) against the oracle."""
     scene = pt_scene("cbox_envmap")
     w, h, spp = 36, 28, 6
     want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
     pt = make_pt(srt, scene, w, h, 8, True)
-    for mode in (0, 1, 4):
+    rays = set()
+    for mode in (0, 1, 2, 4):
         pt.set_kernel(mode)
+        pt.ray_count(reset=True)
         assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
-    pt.set_kernel(2)
-    with pytest.raises(srt.SrtError):
-        pt.render_epoch(8, 1, spp)
+        rays.add(pt.ray_count()[0])
+    assert len(rays) == 1
     pt.close()
 
 
@@ -508,7 +510,8 @@ def test_random_scenes_all_kernels(srt):
     from _cases import random_pt_scene
 
     checked = 0
-    for seed in list(range(300, 340)) + list(range(100000, 100016)):     # the second range also draws delta / environment lights
+    # the second range also draws delta / uniform environment lights, the third image environment maps
+    for seed in list(range(300, 340)) + list(range(100000, 100016)) + list(range(200000, 200010)):
         scene, w, h, depth, use_bvh, spp = random_pt_scene(seed)
         try:
             want = H.OraclePT(scene, w, h, depth, use_bvh).epoch(seed, 3, spp)
