@@ -332,7 +332,10 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC2T
 #define SRT_WAVE_OCC2T 4
 #endif
-__global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WAVE_OCC2) : SRT_WAVE_OCC) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+#ifndef SRT_WAVE_OCC3T
+#define SRT_WAVE_OCC3T 4
+#endif
+__global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WAVE_OCC2) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC)) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
