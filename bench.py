@@ -397,7 +397,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms,
-                "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_launches": wave_launches, "epoch_device_ms": epoch_ms,
+                "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_launches": wave_launches,
+                "step_span_ms_on_its_stream": epoch_ms,   # start-to-end of a step on its own stream; the other stream's step shares the GPU meanwhile
                 "algorithmic_bytes_per_ray": bpr,
                 "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
                 "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d); "
