@@ -26,8 +26,16 @@
  * HDR_Image: row 0 = bottom (util/hdr_image.cpp:54-57).  Matrices are 16 floats in Mat4::data order
  * (column-major, lib/mat4.h).
  *
+ *   srt_pt_tonemap         <- HDR_Image::tonemap_to              util/hdr_image.cpp:161-187 (Spectrum::to_srgb lib/spectrum.h:61-75)
+ *   srt_pt_add_light / set_env_light / set_env_map / add_sphere_light
+ *                          <- Pathtracer::build_lights           rays/pathtracer.cpp:26-64 (rays/light.cpp, student/env_light.cpp)
+ *
  * Status codes and srt_last_error(): see srt_raster.h.  No CPU fallback: srt_pt_create fails without a
  * HIP device.
+ *
+ * Threads: a context is used from one host thread at a time (the reference's Pathtracer owns one worker per render).
+ * The *_device entry points only enqueue work on the given stream; epochs enqueued on different streams may overlap on
+ * the GPU (the library keeps one set of epoch scratch buffers per stream).
  */
 #ifndef SRT_PT_H
 #define SRT_PT_H
