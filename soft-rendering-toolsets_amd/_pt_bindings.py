@@ -229,7 +229,7 @@ class Pathtracer:
 
     def set_kernel(self, mode: int) -> None:
         """0 auto, 1 lane per pixel, 2 wave-uniform sweeps, 3 the same with section stamps, 4 lane per sample,
-        5 persistent waves with the flattened per-lane walk (include/srt_pt.h)."""
+        5 persistent waves with the flattened per-lane walk, 6 streamed form: logic + ray-cast kernels (include/srt_pt.h)."""
         self._check(self._lib, self._lib.srt_pt_set_kernel(self._ctx, int(mode)))
 
     def section_cycles(self, reset: bool = False) -> dict:

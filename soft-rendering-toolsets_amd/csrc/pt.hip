@@ -278,9 +278,18 @@ struct srt_pt {
     float* d_records = nullptr; size_t records_floats = 0;   // wave kernel: per-bounce records
     float* d_running = nullptr; size_t running_floats = 0;   // (sum, count) across the launches of one epoch
     unsigned long long* d_queue = nullptr;                   // wave kernel: queue head (+ section stamps)
+    // streamed form (pt_stream.h): saved path state, ray queue, hits, counters
+    uint32_t* d_state = nullptr; size_t state_words = 0;
+    float4* d_ray_o = nullptr; size_t ray_o_n = 0;
+    float4* d_ray_d = nullptr; size_t ray_d_n = 0;
+    uint32_t* d_ray_id = nullptr; size_t ray_id_n = 0;
+    uint2* d_hits = nullptr; size_t hits_n = 0;
+    StreamCounters* d_sc = nullptr;
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
+  int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0;   // pt_cast_kernel's launch shape for the committed scene (0: not derived yet)
+  uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
   int elide = 0;                            // srt_pt_set_elision
   unsigned long long last_counters[C_COUNT] = {0};
@@ -383,6 +392,21 @@ bool flat_walk_fits(const FlatScene& F) {
   return fits;
 }
 
+// The streamed form (pt_stream.h): any number of objects, as long as a hit still packs into one word
+// (object slot << shift | triangle) and the references fit the 30-bit field of an LDS frame.
+uint32_t stream_obj_shift(const FlatScene& F) {
+  uint32_t bits = 1;
+  while ((1ull << bits) <= F.objects.size()) bits++;      // the object field is never all ones: 0xFFFFFFFF / ..FE stay free
+  return 32u - bits;
+}
+bool stream_fits(const FlatScene& F) {
+  if (F.objects.empty() || F.objects.size() >= (1u << 24)) return false;
+  if (F.tris.size() >= (1ull << stream_obj_shift(F)) || F.tris.size() >= (1u << 26) || F.blas_recs.size() >= (1u << 29)) return false;
+  for (const WaveInterior& w : F.wave_tlas)
+    if ((w.l_ref < 0 && w.l_cnt > kFlatMaxLeafObjects) || (w.r_ref < 0 && w.r_cnt > kFlatMaxLeafObjects)) return false;
+  return true;
+}
+
 int wave_trav(const srt_pt* pt) {
   const FlatScene& F = pt->built.flat;
   const int m = pt->kernel_mode;
@@ -395,6 +419,9 @@ int wave_trav(const srt_pt* pt) {
   if (m == 2) return sweeps_fit ? (blas ? 1 : 0) : -1;
   if (m == 3) return (sweeps_fit && !lights) ? (blas ? 1 : 0) : -1;
   if (m == 5) return (flat_fits && !lights) ? 2 : -1;
+  if (m == 6) return stream_fits(F) ? 3 : -1;
+  // auto: scenes with a real BVH<Triangle> or with more objects than the sweeps take go through the streamed form
+  if ((blas || !sweeps_fit) && stream_fits(F)) return 3;
   // auto: the sweeps whenever the scene has few enough objects.  Meshes with a real BVH<Triangle> are walked per lane
   // inside the sweeps, only by the rays that can reach them and compacted over the wave (object_testN): 407 / 771 / 1458
   // Mrays/s on the 131 k / 8 k / 512-triangle test scenes against 367 / 475 / 676 for the lane-per-sample kernel,
@@ -429,11 +456,14 @@ int time_end(srt_pt* pt, hipStream_t s) {
   return SRT_OK;
 }
 
+int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out);
+
 int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
   const int trav = wave_trav(pt);
+  if (trav == 3) return render_epoch_stream(pt, s, seed, sample_base, samples, d_tiles_out);
   const bool stamp = pt->kernel_mode == 3;
   const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
   const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
@@ -516,6 +546,106 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   return SRT_OK;
 }
 
+// One epoch in the streamed form (pt_stream.h): per launch of <= 64 samples per pixel a fixed number of generations, each
+// one logic kernel (pt_wave_kernel<.., TRAV = 3, ..>: consume hits, shade, refill, emit rays) and one ray-cast kernel;
+// then the ordered per-pixel reduction.  Nothing here waits for the device.
+int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
+  const TileMap& T = pt->tiles;
+  const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
+  const FlatScene& F = pt->built.flat;
+  const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
+  const bool two = elision_provable(pt);
+  const uint32_t burst = two ? 2u : kBurst;
+  int st;
+  // the cast kernel's launch shape: frames per lane from the scene's tree depths, as many waves per CU as the LDS holds
+  const uint32_t depth = F.max_tlas_depth + F.max_blas_depth + 1u;
+  if (pt->cast_blocks == 0) {
+    int cus = 0;
+    SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
+    const size_t per_wave = (size_t)depth * 3u * 64u * sizeof(uint32_t);
+    int best_waves = 0;
+    for (int w : {4, 2, 1}) {
+      const size_t lds = per_wave * (size_t)w;
+      if (lds > 160u * 1024u) continue;
+      if (hipFuncSetAttribute((const void*)pt_cast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pt_cast_kernel, 64 * w, lds) != hipSuccess || per_cu < 1) continue;
+      if (per_cu * w > best_waves) { best_waves = per_cu * w; pt->cast_threads = 64 * w; pt->cast_blocks = per_cu * cus; pt->cast_lds = lds; }
+    }
+    if (best_waves == 0) return srt::fail(SRT_ERR_UNSUPPORTED, "the ray-cast kernel's traversal stack (%u frames per lane) does not fit into LDS", depth);
+    SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
+    if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u frames per lane), %d waves/CU\n",
+                                     pt->cast_blocks, pt->cast_threads, pt->cast_lds, depth, best_waves);
+  }
+  const uint32_t chunk = samples_per_launch(px);
+  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
+  if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
+  if (!B.d_sc) SRT_HIP(hipMalloc(&B.d_sc, sizeof(StreamCounters)));
+  const uint32_t state_words = dl ? (uint32_t)SW_DL_WORDS : (uint32_t)SW_BASE_WORDS;
+  const uint32_t shadow_batches = (uint32_t)((F.delta_lights.size() + 2) / 3);
+  const DScene DS = device_scene(pt);
+  for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
+    const uint32_t n = samples - done < chunk ? samples - done : chunk;
+    WaveParams P{};
+    P.T = T; P.seed = seed; P.sample_base = sample_base + done; P.samples = n;
+    P.singles = (n >= 4 * burst) ? burst + n % burst : n % burst;   // as the persistent kernel: a few one-sample units at the end
+    P.groups3 = (n - P.singles) / burst;
+    P.units3 = px * P.groups3;
+    P.total_units = px * (P.groups3 + P.singles);
+    // path slots: every unit its own while they are few, else a fixed population that is refilled from the unit queue
+    uint32_t want_slots = pt->stream_slots ? pt->stream_slots : (getenv("SRT_STREAM_SLOTS") ? (uint32_t)atoi(getenv("SRT_STREAM_SLOTS")) : (1u << 20));
+    if (want_slots < 256u) want_slots = 256u;
+    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(((uint64_t)P.total_units + 255u) / 256u * 256u, (want_slots + 255u) / 256u * 256u);
+    if (n && nlanes) {
+      P.nlanes = nlanes;
+      if ((st = ensure(&B.d_records, &B.records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_state, &B.state_words, (size_t)nlanes * SW_DL_WORDS)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_o, &B.ray_o_n, (size_t)nlanes * 3)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_d, &B.ray_d_n, (size_t)nlanes * 3)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_id, &B.ray_id_n, (size_t)nlanes * 3)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_hits, &B.hits_n, (size_t)nlanes * 3)) != SRT_OK) return st;
+      (void)state_words;
+      P.sample_out = B.d_samples; P.records = B.d_records; P.npix = px; P.chunk = kChunk;
+      P.queue_head = &B.d_sc->queue_head; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1;
+      P.stamps = nullptr; P.flat_ready = 0; P.flat_interior = 0;
+      P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_d; P.ray_id = B.d_ray_id; P.hits = B.d_hits; P.sc = B.d_sc;
+      P.obj_shift = stream_obj_shift(F);
+      SRT_HIP(hipMemsetAsync(B.d_sc, 0, sizeof(StreamCounters), s));
+      SRT_HIP(hipMemsetAsync(B.d_state, 0, (size_t)nlanes * sizeof(uint32_t), s));   // the flags plane: every slot idle
+      // generations: list scheduling of units of <= M batches on nlanes slots
+      const uint64_t M = 1ull + (uint64_t)burst * pt->max_depth * (1ull + (dl ? shadow_batches : 0ull));
+      const uint64_t gens = ((uint64_t)P.total_units * M + nlanes - 1) / nlanes + M + 2;
+      CastParams C{};
+      C.ray_o = B.d_ray_o; C.ray_d = B.d_ray_d; C.ray_id = B.d_ray_id; C.hits = B.d_hits; C.nlanes = nlanes;
+      C.depth = depth; C.obj_shift = P.obj_shift;
+      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 16u;
+      C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
+      if (C.fetch_min < 1u) C.fetch_min = 1u;
+      const dim3 lgrid(nlanes / 256u), lblock(256);
+      if ((st = time_begin(pt, s)) != SRT_OK) return st;
+      for (uint64_t g = 0; g < gens; g++) {
+        P.gen = (uint32_t)g;
+#define SRT_LAUNCH_LOGIC(DL_, NR_)                                                                                               \
+  pt_wave_kernel<false, 3, DL_, NR_><<<lgrid, lblock, 0, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,         \
+                                                                DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, \
+                                                                P.sample_out)
+        if (two) SRT_LAUNCH_LOGIC(false, 2); else if (dl) SRT_LAUNCH_LOGIC(true, 3); else SRT_LAUNCH_LOGIC(false, 3);
+#undef SRT_LAUNCH_LOGIC
+        C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1];
+        pt_cast_kernel<<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
+      }
+      SRT_HIP(hipGetLastError());
+      if ((st = time_end(pt, s)) != SRT_OK) return st;
+    }
+    const int first = done == 0, last = done + chunk >= samples;
+    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
+    SRT_HIP(hipGetLastError());
+    if (samples == 0) break;
+  }
+  return SRT_OK;
+}
+
 // One epoch with one lane per sample (general scenes): launches of <= 64 samples per pixel + ordered reduction.
 int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
   const TileMap& T = pt->tiles;
@@ -583,6 +713,8 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     for (auto& kv : pt->epoch_buffers) {
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
+      (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id);
+      (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc);
     }
     for (auto& v : {&pt->timed, &pt->spare})
       for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -720,6 +852,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
       return st;
   }
   pt->committed = true;
+  pt->cast_blocks = 0;                                    // the ray-cast kernel's stack depth follows the scene
   return SRT_OK;
 }
 
@@ -760,8 +893,8 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
 
 int srt_pt_set_kernel(srt_pt* pt, int mode) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_kernel: NULL context");
-  if (mode < 0 || mode > 5)
-    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped), 4 (per-lane, lane per sample) or 5 (persistent waves, flattened per-lane walk)");
+  if (mode < 0 || mode > 6)
+    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped), 4 (per-lane, lane per sample), 5 (persistent waves, flattened per-lane walk) or 6 (streamed: logic + ray-cast kernels)");
   pt->kernel_mode = mode;
   return SRT_OK;
 }
@@ -781,6 +914,9 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
                        pt->built.flat.objects.size());
     if (pt->kernel_mode == 5 && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened-walk kernel needs 1..31 objects (scene has %zu)", pt->built.flat.objects.size());
+    if (pt->kernel_mode == 6 && !wave_kernel_applies(pt))
+      return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed form cannot pack this scene's hits (%zu objects, %zu triangles)", pt->built.flat.objects.size(),
+                       pt->built.flat.tris.size());
     if (wave_kernel_applies(pt)) {
       st = render_epoch_wave(pt, s, seed, sample_base, samples, d_tiles_out);
       if (st != SRT_OK) return st;

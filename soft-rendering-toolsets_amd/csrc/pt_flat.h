@@ -33,6 +33,15 @@ namespace srt {
 // Before the nearer child returns a/b hold cur_far_t; afterwards a = its distance, b = its triangle.
 struct FlatFrame { int32_t second; float a; uint32_t b; uint32_t fl; };
 
+// Where the frames live is the caller's choice: ArrayStack is a per-lane array (scratch memory on the device); the streamed
+// ray-cast kernel (pt_stream.h) keeps 12-byte packed frames in LDS, [depth][word][lane], which is conflict-free however
+// the lanes' depths differ.
+struct ArrayStack {
+  FlatFrame* p;
+  SRT_DEV FlatFrame load(int i) const { return p[i]; }
+  SRT_DEV void store(int i, const FlatFrame& f) const { p[i] = f; }
+};
+
 constexpr int kFlatStack = kMaxTlasDepth + kMaxBlasDepth;
 constexpr uint32_t kFlatMaxLeafObjects = 7;   // objects per BVH<Object> leaf the 3-bit count can describe (the reference builds 1)
 
@@ -99,7 +108,8 @@ SRT_DEV void flat_begin(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 
 // ---- the steps of the walk; each requires the state named in its comment ----
 
 // mode == NODE, cur >= 0: an interior record of the current tree.
-SRT_DEV void flat_interior(FlatState& F, FlatFrame* stack, const DScene& S) {
+template <typename StackT>
+SRT_DEV void flat_interior(FlatState& F, const StackT& stack, const DScene& S) {
   const WaveInterior* __restrict__ rp = F.level ? (S.blas_recs + F.rec_base) : S.wave_tlas;
   const WaveInterior W = rp[F.cur];
   float t1x = F.tx, t1y = F.ty, t2x = F.tx, t2y = F.ty;
@@ -115,7 +125,7 @@ SRT_DEV void flat_interior(FlatState& F, FlatFrame* stack, const DScene& S) {
     f.a = hb ? (cl ? t2x : t1x) : F.b0;        // cur_far_t: the other child's times, or ray.dist_bounds
     f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : F.b1);
     f.fl = hb ? 1u : 0u;
-    stack[F.sp++] = f;
+    stack.store(F.sp++, f);
     F.cur = cl ? lref : rref;
     F.tx = cl ? t1x : t2x;
     F.ty = cl ? t1y : t2y;
@@ -197,8 +207,9 @@ SRT_DEV void flat_object(FlatState& F, const DScene& S) {
 SRT_DEV bool flat_plain_frame(const FlatState& F) { return F.sp != 0 && !(F.level && F.sp == F.base_sp); }
 
 // mode == UNWIND with an ordinary frame on top.
-SRT_DEV void flat_pop(FlatState& F, FlatFrame* stack) {
-  const FlatFrame f = stack[F.sp - 1];
+template <typename StackT>
+SRT_DEV void flat_pop(FlatState& F, const StackT& stack) {
+  const FlatFrame f = stack.load(F.sp - 1);
   // hipcc 7.2 -O2/-O3 (gfx950) has been seen to drop the `cur = f.second` below when this function is inlined
   // behind flat_interior (the lane then re-walks the nearer child instead of the farther one; -O1 and the host
   // build are right, step traces compared in round 1).  Pinning the loaded value in its own VGPR avoids it; the
@@ -212,7 +223,7 @@ SRT_DEV void flat_pop(FlatState& F, FlatFrame* stack) {
     FlatFrame g;                                   // keep the nearer child's result in the frame
     g.second = second; g.a = F.ret.dist; g.b = F.ret.tri;
     g.fl = f.fl | 2u | (F.ret.hit ? 4u : 0u) | (F.ret.obj << 3);
-    stack[F.sp - 1] = g;
+    stack.store(F.sp - 1, g);
     F.cur = second; F.tx = f.a; F.ty = __uint_as_float(f.b);
     F.mode = FM_NODE;
   } else {
@@ -263,8 +274,9 @@ SRT_DEV void flat_exit(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 d
 // then the waiting lanes do their leaf / object / exit step together.  Returns when no lane is walking any more, or
 // when `ready_min` lanes with `counts` set have finished their batch (the caller then shades / refills those and
 // calls again; the other lanes keep their place in the tree).
-SRT_DEV void flat_run(FlatState& F, FlatFrame* stack, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1,
+SRT_DEV void flat_run(FlatState& F, FlatFrame* frames, const DScene& S, V3 org, V3 d0, V3 d1, V3 d2, float cb0, float cb1,
                       bool counts, uint32_t ready_min, uint32_t interior_min) {
+  const ArrayStack stack{frames};
   for (;;) {
     if (__ballot(F.mode != FM_DONE) == 0ull) break;
     if ((uint32_t)__popcll(__ballot(counts && F.mode == FM_DONE)) >= ready_min) break;

@@ -126,11 +126,16 @@ bool build_bvh(const std::vector<Box>& boxes, uint32_t max_leaf, HostBVH* out) {
   return true;
 }
 
-uint32_t interior_depth(const HostBVH& b, uint32_t n = 0) {
+// Interior-node nesting of the tree.  Children are allocated after their parent (level order, student/bvh.inl:144-145),
+// so one backward pass over the node array does it - no recursion, however skewed the tree.
+uint32_t interior_depth(const HostBVH& b) {
   if (b.nodes.empty()) return 0;
-  const HostNode& nd = b.nodes[n];
-  if (nd.l == nd.r) return 0;
-  return 1 + std::max(interior_depth(b, nd.l), interior_depth(b, nd.r));
+  std::vector<uint32_t> d(b.nodes.size(), 0u);
+  for (size_t n = b.nodes.size(); n-- > 0;) {
+    const HostNode& nd = b.nodes[n];
+    if (nd.l != nd.r) d[n] = 1u + std::max(d[nd.l], d[nd.r]);
+  }
+  return d[0];
 }
 
 // Mat4 * Vec3 with perspective divide (lib/mat4.h:125-131).

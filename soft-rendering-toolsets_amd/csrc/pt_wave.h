@@ -40,6 +40,7 @@
 
 #include "pt_trace.h"
 #include "pt_flat.h"
+#include "pt_stream.h"
 
 namespace srt {
 
@@ -69,6 +70,15 @@ struct WaveParams {
   uint32_t npix;             // pixel slots of the launch; sample_out is [sample][pixel slot] so that the reduction reads coalesced
   uint32_t flat_ready;       // TRAV 2: lanes with a finished batch that make the wave leave the walk
   uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
+  // TRAV 3 (streamed form, pt_stream.h): one invocation = one generation; nlanes = path slots
+  uint32_t* state;           // [word][slot] saved path state
+  float4* ray_o;             // ray queue of this generation (NR * nlanes entries)
+  float4* ray_d;
+  uint32_t* ray_id;
+  const uint2* hits;         // [batch slot][path slot] results of the previous generation's rays
+  StreamCounters* sc;
+  uint32_t gen;              // generation number
+  uint32_t obj_shift;        // packed hit = object slot << obj_shift | triangle
 };
 
 // Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
@@ -151,13 +161,14 @@ SRT_DEV bool box_hit_inv(const float* __restrict__ bx, V3 o, V3 inv, float& tx, 
 
 constexpr uint32_t kRetMiss = 0xFFFFFFFFu;
 constexpr uint32_t kRetMissEnv = 0xFFFFFFFEu;   // miss, and the environment light is visible along the (camera) ray
-SRT_DEV uint32_t pack_ret(const Hit& h) { return h.hit ? ((h.obj << 27) | h.tri) : kRetMiss; }
-SRT_DEV Hit unpack_ret(float dist, uint32_t id) {
+// (the sweep builds take <= 16 objects: 5 + 27 bits; the streamed build passes the scene's own split)
+SRT_DEV uint32_t pack_ret(const Hit& h, uint32_t shift = 27u) { return h.hit ? ((h.obj << shift) | h.tri) : kRetMiss; }
+SRT_DEV Hit unpack_ret(float dist, uint32_t id, uint32_t shift = 27u) {
   Hit h;
   h.hit = id != kRetMiss;
   h.dist = h.hit ? dist : 0.0f;
-  h.obj = h.hit ? (id >> 27) : 0;
-  h.tri = h.hit ? (id & 0x07FFFFFFu) : 0;
+  h.obj = h.hit ? (id >> shift) : 0;
+  h.tri = h.hit ? (id & ((1u << shift) - 1u)) : 0;
   return h;
 }
 SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0; return h; }
@@ -342,7 +353,11 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
                                                       const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
                                                       float* __restrict__ a_records, float* __restrict__ a_samples) {
   static_assert(NR == 3 || (NR == 2 && TRAV != 2 && !DL), "two-ray batches: sweep builds without delta / environment lights only");
+  static_assert(!(STAMP && TRAV == 3), "the streamed build has no section stamps");
   constexpr int C = NR - 1;                              // slot of the indirect ray
+  if constexpr (TRAV == 3) {
+    if (P_in.sc->units_done >= (unsigned long long)P_in.total_units) return;   // every unit is finished: the remaining generations are no-ops
+  }
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
@@ -354,7 +369,8 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* const cidx = s_cidx + (TRAV == 1 ? wave * NR * 64 : 0);
   const uint32_t nobj = S.nobjects;
-  const uint32_t Q = S.use_bvh ? S.wave_q : 0u;
+  const uint32_t Q = (S.use_bvh && TRAV != 3) ? S.wave_q : 0u;
+  const uint32_t oshift = (TRAV == 3) ? P.obj_shift : 27u;   // packed hit = object slot << oshift | triangle
   unsigned long long stamp_acc[ST_COUNT_] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_t = 0;
   if (STAMP) stamp_t = __builtin_readcyclecounter();
@@ -417,10 +433,48 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
   // wave-uniform queue window
   uint32_t chunk_next = 0, chunk_end = 0;
   bool queue_empty = false;
+  uint32_t units_finished = 0;                           // TRAV 3: units this lane completed (or found outside the image)
 
-  for (;;) {
+  // TRAV == 3 (pt_stream.h): this invocation is one generation.  The slot's state comes from HBM, pass 0 of the loop
+  // consumes the hits of the batch emitted by the previous generation (step 3 as it stands), pass 1 refills idle slots,
+  // appends the next batch's rays to the queue and saves the state.
+#define ST(w) P.state[(size_t)(w) * P.nlanes + lane_global]
+  if constexpr (TRAV == 3) {
+    if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
+    const uint32_t fw = ST(SW_FLAGS);
+    alive = (fw & 1u) != 0;
+    if (alive) {
+      burst = (fw & 2u) != 0; actA = (fw & 4u) != 0; actB = (fw & 8u) != 0; discrete = (fw & 16u) != 0;
+      sh_phase = (fw & 32u) != 0; sa1 = (fw & 64u) != 0; sa2 = (fw & 128u) != 0;
+      level = (fw >> 8) & 0xffu; depth = (fw >> 16) & 0xffu;
+      px = ST(SW_PX); py = ST(SW_PY); pixel_slot = ST(SW_PIXEL_SLOT);
+      const uint32_t sw = ST(SW_SAMPLES);
+      s_first = sw & 0xffffu; s_cur = (sw >> 16) & 0x3fffu; s_count = sw >> 30;
+      pend[0] = ST(SW_PEND0);
+      if (NR > 2) pend[NR - 2] = ST(SW_PEND1);
+      rng.state = (uint64_t)ST(SW_RNG_LO) | ((uint64_t)ST(SW_RNG_HI) << 32);
+      rng.inc = (((((uint64_t)(py * S.w + px)) << 32) | (uint64_t)(P.sample_base + s_cur)) << 1) | 1ull;   // Rng::key's increment
+      org = v3(__uint_as_float(ST(SW_ORG)), __uint_as_float(ST(SW_ORG + 1)), __uint_as_float(ST(SW_ORG + 2)));
+      d[C] = v3(__uint_as_float(ST(SW_DC)), __uint_as_float(ST(SW_DC + 1)), __uint_as_float(ST(SW_DC + 2)));
+      cb0 = __uint_as_float(ST(SW_CB0)); cb1 = __uint_as_float(ST(SW_CB1));
+      att = spec(__uint_as_float(ST(SW_ATT)), __uint_as_float(ST(SW_ATT + 1)), __uint_as_float(ST(SW_ATT + 2)));
+      pdf4 = __uint_as_float(ST(SW_PDF4)); pdf_area = __uint_as_float(ST(SW_PDF_AREA));
+      if constexpr (DL) {
+        d[0] = v3(__uint_as_float(ST(SW_D0)), __uint_as_float(ST(SW_D0 + 1)), __uint_as_float(ST(SW_D0 + 2)));
+        d[1] = v3(__uint_as_float(ST(SW_D1)), __uint_as_float(ST(SW_D1 + 1)), __uint_as_float(ST(SW_D1 + 2)));
+        light_i = ST(SW_LIGHT_I); held_chit = ST(SW_HELD);
+        pl = spec(__uint_as_float(ST(SW_PL)), __uint_as_float(ST(SW_PL + 1)), __uint_as_float(ST(SW_PL + 2)));
+        dA_keep = spec(__uint_as_float(ST(SW_DA)), __uint_as_float(ST(SW_DA + 1)), __uint_as_float(ST(SW_DA + 2)));
+        d6_keep = spec(__uint_as_float(ST(SW_D6)), __uint_as_float(ST(SW_D6 + 1)), __uint_as_float(ST(SW_D6 + 2)));
+        dC_keep = v3(__uint_as_float(ST(SW_DCK)), __uint_as_float(ST(SW_DCK + 1)), __uint_as_float(ST(SW_DCK + 2)));
+        sb1[0] = __uint_as_float(ST(SW_SB1)); sb1[1] = __uint_as_float(ST(SW_SB1 + 1)); sb1[2] = __uint_as_float(ST(SW_SB1 + 2));
+      }
+    }
+  }
+
+  for (int pass = 0;; pass++) {
     // ---------------- 1. refill idle lanes ----------------
-    const unsigned long long need = __ballot(!alive);
+    const unsigned long long need = (TRAV != 3 || pass == 1) ? __ballot(!alive) : 0ull;
     if (need != 0ull && !(queue_empty && chunk_next == chunk_end)) {
       const uint32_t want = (uint32_t)__popcll(need);
       const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -429,11 +483,12 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
         if (chunk_next == chunk_end) {
           if (queue_empty) break;
           unsigned long long start = 0;
-          if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)P.chunk);
+          const uint32_t grab = (TRAV == 3) ? want - given : P.chunk;   // the streamed build cannot keep units for a later cycle
+          if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)grab);
           start = __shfl(start, 0);
           if (start >= P.total_units) { queue_empty = true; break; }
           chunk_next = (uint32_t)start;
-          chunk_end = (uint32_t)(start + P.chunk < P.total_units ? start + P.chunk : P.total_units);
+          chunk_end = (uint32_t)(start + grab < P.total_units ? start + grab : P.total_units);
         }
         const uint32_t avail = chunk_end - chunk_next;
         const uint32_t take = avail < want - given ? avail : want - given;
@@ -477,12 +532,77 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
           actA = s_count > 1;                           // slot usage of a burst: ray j exists iff j < s_count
           actB = s_count > 2;
           need_begin = true;
+        } else {
+          units_finished++;                             // a padding pixel of an edge tile: nothing to render
         }
       }
     }
-    if (__ballot(alive) == 0ull) {
-      if (queue_empty && chunk_next == chunk_end) break;
-      continue;
+    if constexpr (TRAV == 3) {
+      if (pass == 1) {
+        // ---- the next batch's rays to the queue (slot-major per wave, one atomic per wave), the slot's state to HBM ----
+        bool eact[NR];
+        float eb1[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) { eact[r] = alive; eb1[r] = cb1; }
+        if (DL && sh_phase) {
+          if (NR > 1) eact[1] = alive && sa1;
+          if (NR > 2) eact[NR - 1] = alive && sa2;
+#pragma unroll
+          for (int r = 0; r < NR; r++) eb1[r] = sb1[r];
+        } else if (burst) { if (NR > 1) eact[1] = alive && actA; if (NR > 2) eact[NR - 1] = alive && actB; }
+        else if (NR == 3) { eact[0] = alive && actA; eact[1] = alive && actB; }
+        uint32_t epos[NR], etotal = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          const unsigned long long m = __ballot(eact[r]);
+          epos[r] = etotal + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          etotal += (uint32_t)__popcll(m);
+        }
+        if (etotal != 0u) {
+          uint32_t ebase = 0;
+          if (lane == 0) ebase = atomicAdd(&P.sc->nrays[P.gen & 1u], etotal);
+          ebase = (uint32_t)__shfl((int)ebase, 0);
+#pragma unroll
+          for (int r = 0; r < NR; r++) {
+            if (eact[r]) {
+              const uint32_t i = ebase + epos[r];
+              P.ray_o[i] = make_float4(org.x, org.y, org.z, cb0);
+              P.ray_d[i] = make_float4(d[r].x, d[r].y, d[r].z, eb1[r]);
+              P.ray_id[i] = (lane_global << 2) | (uint32_t)r;
+            }
+          }
+        }
+        ST(SW_FLAGS) = (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
+                       (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16);
+        if (alive) {
+          ST(SW_PX) = px; ST(SW_PY) = py; ST(SW_PIXEL_SLOT) = pixel_slot;
+          ST(SW_SAMPLES) = s_first | (s_cur << 16) | (s_count << 30);
+          ST(SW_PEND0) = pend[0];
+          if (NR > 2) ST(SW_PEND1) = pend[NR - 2];
+          ST(SW_RNG_LO) = (uint32_t)rng.state; ST(SW_RNG_HI) = (uint32_t)(rng.state >> 32);
+          ST(SW_ORG) = __float_as_uint(org.x); ST(SW_ORG + 1) = __float_as_uint(org.y); ST(SW_ORG + 2) = __float_as_uint(org.z);
+          ST(SW_DC) = __float_as_uint(d[C].x); ST(SW_DC + 1) = __float_as_uint(d[C].y); ST(SW_DC + 2) = __float_as_uint(d[C].z);
+          ST(SW_CB0) = __float_as_uint(cb0); ST(SW_CB1) = __float_as_uint(cb1);
+          ST(SW_ATT) = __float_as_uint(att.r); ST(SW_ATT + 1) = __float_as_uint(att.g); ST(SW_ATT + 2) = __float_as_uint(att.b);
+          ST(SW_PDF4) = __float_as_uint(pdf4); ST(SW_PDF_AREA) = __float_as_uint(pdf_area);
+          if constexpr (DL) {
+            ST(SW_D0) = __float_as_uint(d[0].x); ST(SW_D0 + 1) = __float_as_uint(d[0].y); ST(SW_D0 + 2) = __float_as_uint(d[0].z);
+            ST(SW_D1) = __float_as_uint(d[1].x); ST(SW_D1 + 1) = __float_as_uint(d[1].y); ST(SW_D1 + 2) = __float_as_uint(d[1].z);
+            ST(SW_LIGHT_I) = light_i; ST(SW_HELD) = held_chit;
+            ST(SW_PL) = __float_as_uint(pl.r); ST(SW_PL + 1) = __float_as_uint(pl.g); ST(SW_PL + 2) = __float_as_uint(pl.b);
+            ST(SW_DA) = __float_as_uint(dA_keep.r); ST(SW_DA + 1) = __float_as_uint(dA_keep.g); ST(SW_DA + 2) = __float_as_uint(dA_keep.b);
+            ST(SW_D6) = __float_as_uint(d6_keep.r); ST(SW_D6 + 1) = __float_as_uint(d6_keep.g); ST(SW_D6 + 2) = __float_as_uint(d6_keep.b);
+            ST(SW_DCK) = __float_as_uint(dC_keep.x); ST(SW_DCK + 1) = __float_as_uint(dC_keep.y); ST(SW_DCK + 2) = __float_as_uint(dC_keep.z);
+            ST(SW_SB1) = __float_as_uint(sb1[0]); ST(SW_SB1 + 1) = __float_as_uint(sb1[1]); ST(SW_SB1 + 2) = __float_as_uint(sb1[2]);
+          }
+        }
+        break;
+      }
+    } else {
+      if (__ballot(alive) == 0ull) {
+        if (queue_empty && chunk_next == chunk_end) break;
+        continue;
+      }
     }
     SECTION_END(ST_REFILL)
 
@@ -512,7 +632,17 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
     else if (burst) { if (NR > 1) act[1] = alive && actA; if (NR > 2) act[NR - 1] = alive && actB; }
     else if (NR == 3) { act[0] = alive && actA; act[1] = alive && actB; }
     bool batch_ready = alive;                            // the lane's batch has been traced completely
-    if constexpr (TRAV == 2) {
+    if constexpr (TRAV == 3) {
+      // the cast kernel traced the batch: {distance, packed ids} per slot
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        res[r] = no_hit();
+        if (act[r]) {
+          const uint2 hv = P.hits[(size_t)r * P.nlanes + lane_global];
+          res[r] = unpack_ret(__uint_as_float(hv.x), hv.y, oshift);
+        }
+      }
+    } else if constexpr (TRAV == 2) {
       // general scenes: one flattened per-lane walk over both tree levels for the slots that carry a ray
       if (need_begin) {
         cnt.v[C_RAYS] += 1u + (actA ? 1u : 0u) + (actB ? 1u : 0u);
@@ -695,9 +825,9 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
       if (shadow_returned) {
       } else if (burst) {
         // burst order: slot 0 = sample s_first (continues now), the other slots = the next samples (parked)
-        chit = pack_ret(res[0]);
+        chit = pack_ret(res[0], oshift);
 #pragma unroll
-        for (int j = 0; j < NR - 1; j++) pend[j] = pack_ret(res[j + 1]);
+        for (int j = 0; j < NR - 1; j++) pend[j] = pack_ret(res[j + 1], oshift);
         if constexpr (DL) {
           if (S.env_type != 0u) {
             // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
@@ -724,7 +854,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
         }
         float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
         rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
-        chit = pack_ret(res[C]);
+        chit = pack_ret(res[C], oshift);
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
           Spec eA = spec(0, 0, 0), eB = spec(0, 0, 0);
@@ -743,7 +873,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
             if (DL && S.ndelta != 0u && luma(att) != 0.0f) {
               // point_lighting comes first in the sum: hold the two terms until the shadow rays are back
               dA_keep = direct; d6_keep = d6; pl = spec(0, 0, 0);
-              light_i = 0; held_chit = pack_ret(res[C]); dC_keep = d[C];
+              light_i = 0; held_chit = pack_ret(res[C], oshift); dC_keep = d[C];
               sh_phase = true; more_shadow = true;
             } else {
               radiance = radiance + direct;
@@ -756,7 +886,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
             rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
           }
         }
-        chit = pack_ret(res[C]);
+        chit = pack_ret(res[C], oshift);
       }
       if constexpr (DL) {
         if (more_shadow) {
@@ -779,7 +909,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
       uint32_t mi = 0;
       for (int guard = 0; guard < 3 && !need_shade && alive && !(DL && more_shadow); guard++) {
         const bool miss_env = DL && chit == kRetMissEnv;   // a camera ray that left the scene into the environment light
-        const Hit ch = unpack_ret(0.0f, miss_env ? kRetMiss : chit);
+        const Hit ch = unpack_ret(0.0f, miss_env ? kRetMiss : chit, oshift);
         bool terminal = !ch.hit;                         // student/pathtracer.cpp:174-218
         e = spec(0, 0, 0);
         if (miss_env && level == 0) {
@@ -824,12 +954,13 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
           burst = true;                                 // "the ray that led here was a camera ray"
         } else {
           alive = false;
+          units_finished++;
         }
       }
       SECTION_END(ST_TERMINATE)
       if (need_shade && alive) {
         const Material& m = S.materials[mi];
-        const Hit ch = unpack_ret(0.0f, chit);
+        const Hit ch = unpack_ret(0.0f, chit, oshift);
         Ray ray;
         ray.o = org; ray.d = d[C]; ray.b0 = cb0; ray.b1 = cb1;
         if (level == 0) {
@@ -896,9 +1027,15 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
 #undef SECTION_END
 
 #undef SLOT
+#undef ST
   unsigned long long r = cnt.v[C_RAYS], rt = (NR == 3) ? cnt.v[C_RAYS] : traced;
-  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); }
-  if (lane == 0) { atomicAdd(P.ray_counter, r); if (NR == 2) atomicAdd(P.elided_counter, r - rt); }
+  unsigned long long uf = units_finished;
+  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); if (TRAV == 3) uf += __shfl_down(uf, off); }
+  if (lane == 0) {
+    if (TRAV != 3 || r != 0ull) atomicAdd(P.ray_counter, r);
+    if (NR == 2 && (TRAV != 3 || r != rt)) atomicAdd(P.elided_counter, r - rt);
+    if (TRAV == 3 && uf != 0ull) atomicAdd(&P.sc->units_done, uf);
+  }
 }
 
 // Adds the samples of each pixel in sample order with do_trace's validity filter.  A render of more than one

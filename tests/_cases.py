@@ -132,6 +132,10 @@ def pt_scene(name):
         return scenes.cornell_with_mesh(3, "glass")   # 8*4^3 = 512 triangles -> a real BVH<Triangle>
     if name == "cbox_blob2048_mirror":
         return scenes.cornell_with_mesh(4, "mirror")
+    if name == "cbox_blob131072_glass":
+        # BASELINE configs[4] stand-in at size: Cornell walls + light + mirror sphere + a 131 072-triangle glass mesh
+        # (the Stanford dragon is a missing large blob of the reference checkout; DESIGN.md names the substitute)
+        return scenes.cornell_with_mesh(7, "glass")
     if name == "cbox_refract":
         s = scenes.cornell_box("cbox")
         s["materials"][6] = {"type": scenes.REFRACT, "a": np.ones(3, np.float32), "b": np.zeros(3, np.float32), "ior": 1.5}

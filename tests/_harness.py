@@ -186,6 +186,24 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def check_blas_against_golden(g, k, dump):
+    """BVH<Triangle> of object slot k: `dump(k)` -> (boxes, links, order) compared with the fixture, which holds either the
+    arrays or (meshes of more than 4096 nodes) their SHA-256 digests.  Returns True when the fixture has that mesh."""
+    if f"blas{k}_boxes" in g:
+        bb, bl, bo = dump(k)
+        want_b, want_l, want_o = g[f"blas{k}_boxes"], g[f"blas{k}_links"], g[f"blas{k}_order"]
+        assert np.array_equal(np.ascontiguousarray(bb, np.float32).view(np.uint32), np.ascontiguousarray(want_b, np.float32).view(np.uint32))
+        assert np.array_equal(bl, want_l) and np.array_equal(bo[: len(want_o)], want_o)
+        return True
+    if f"blas{k}_sha256" in g:
+        bb, bl, bo = dump(k)
+        nodes, ntri = (int(v) for v in g[f"blas{k}_nodes"])
+        assert len(bb) == nodes
+        assert [sha(bb), sha(bl), sha(bo[:ntri])] == [str(v) for v in g[f"blas{k}_sha256"]], "BVH<Triangle> arrays differ from the reference"
+        return True
+    return False
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -42,13 +42,20 @@ CASES = [
     ("cbox_envonly", 32, 24, 8, False, 1024, (16, 12, 4)),      # environment light alone (no area lights)
     ("cbox_envmap", 40, 32, 8, True, 2048, (20, 16, 6)),        # Env_Map: bilinear image lookup (acos / atan2), uniform sampling
     ("cbox_spherelight", 40, 32, 8, True, 2048, (20, 16, 6)),   # emissive analytic sphere lit through its triangle approximation
+    # BASELINE configs[4] at size: 131 072-triangle glass mesh in the box, 1024 x 1024; the BVH<Triangle> (80 127 nodes) is
+    # stored as SHA-256 digests of its arrays, the rest as for the other cases
+    ("cbox_blob131072_glass", 1024, 1024, 8, True, 4096, (24, 24, 4)),
 ]
+BIG_BLAS = 4096   # node arrays longer than this are stored as digests
 SEED = 20260331
 
 
 def main():
     assert H.ref_pt_lib() is not None, "build oracle/_ref first: make -C oracle ref"
+    only = sys.argv[1:]
     for name, w, h, depth, use_bvh, n, ep in CASES:
+        if only and name not in only:
+            continue
         scene = pt_scene(name)
         ref = H.RefPT(scene, w, h, depth, use_bvh)
         xs, ys, ss = pt_sample_list(SEED, w, h, n)
@@ -64,7 +71,11 @@ def main():
                 d_ = ref.dump_bvh(k)
                 if d_ is not None and len(d_[0]) > 1:
                     ntri = int(d_[1][0][1])
-                    out.update({f"blas{k}_boxes": d_[0], f"blas{k}_links": d_[1], f"blas{k}_order": d_[2][:ntri].copy()})
+                    if len(d_[0]) > BIG_BLAS:
+                        out.update({f"blas{k}_sha256": np.array([H.sha(d_[0]), H.sha(d_[1]), H.sha(d_[2][:ntri])]),
+                                    f"blas{k}_nodes": np.array([len(d_[0]), ntri], np.int64)})
+                    else:
+                        out.update({f"blas{k}_boxes": d_[0], f"blas{k}_links": d_[1], f"blas{k}_order": d_[2][:ntri].copy()})
         if ep:
             ew, eh, spp = ep
             r2 = H.RefPT(scene, ew, eh, depth, use_bvh)

@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 
 GOLDENS = sorted(glob.glob(os.path.join(H.GOLDEN, "pt_*.npz")))
 TOL = 1e-4  # north_star tolerance, per channel, L-inf (reported next to the bit-exact verdict)
+# kernel modes (include/srt_pt.h) that take scenes with a real BVH<Triangle>; the second list also honours srt_pt_set_elision
+MESH_KERNEL_MODES = (0, 1, 2, 4, 5, 6)
+MESH_ELISION_MODES = (2, 4, 6)
 
 
 def bits_equal(a, b):
@@ -243,12 +246,12 @@ def test_delta_lights(srt):
     assert not bits_equal(want, plain)
     pt = make_pt(srt, scene, w, h, 8, True)
     rays = []
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 6):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         assert bits_equal(pt.render_epoch(3, 2, spp), want), f"kernel mode {mode}"
         rays.append(pt.ray_count()[0])
-    assert rays[0] == rays[1] == rays[2] == rays[3]
+    assert len(set(rays)) == 1
     for mode in (3, 5):
         pt.set_kernel(mode)
         with pytest.raises(srt.SrtError):
@@ -257,15 +260,21 @@ def test_delta_lights(srt):
 
 
 def test_many_objects(srt):
-    """A BVH<Object> of 74 objects (what a particle system becomes): per-lane kernels against the oracle, BVH and list;
-    the wave-uniform builds refuse it."""
+    """A BVH<Object> of 74 objects (what a particle system becomes): the streamed form and the per-lane kernels against the
+    oracle, BVH and list; the wave-uniform sweeps refuse it."""
     scene = pt_scene("cbox_particles")
     w, h, spp = 40, 32, 3
     pt = make_pt(srt, scene, w, h, 6, True)
     want = H.OraclePT(scene, w, h, 6, True).epoch(4, 0, spp)
-    for mode in (0, 1, 4):
+    for mode in (0, 1, 4, 6):                # auto = the streamed form (logic + ray-cast kernels): any number of objects
         pt.set_kernel(mode)
         assert bits_equal(pt.render_epoch(4, 0, spp), want), f"kernel mode {mode}"
+    pt.set_kernel(6)
+    pt.set_elision(True)
+    pt.rays_elided(reset=True)
+    assert bits_equal(pt.render_epoch(4, 0, spp), want) and pt.rays_elided() > 0
+    pt.set_elision(False)
+    pt.set_kernel(0)
     org, d, b = random_rays(5, 3000)
     assert bits_equal(pt.hit(org, d, b), H.OraclePT(scene, w, h, 6, True).hit(org, d, b))
     for mode in (2, 5):
@@ -284,7 +293,7 @@ def test_emissive_sphere(srt):
     w, h, spp = 36, 28, 6
     want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
     pt = make_pt(srt, scene, w, h, 8, True)
-    for mode in (0, 1, 2, 4, 5):
+    for mode in (0, 1, 2, 4, 5, 6):
         pt.set_kernel(mode)
         assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
     pt.close()
@@ -298,7 +307,7 @@ def test_environment_map(srt):
     want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
     pt = make_pt(srt, scene, w, h, 8, True)
     rays = set()
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 6):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
@@ -316,7 +325,7 @@ def test_environment_lights(srt, name):
     w, h, spp = 36, 28, 7
     want = H.OraclePT(scene, w, h, 8, True).epoch(8, 1, spp)
     pt = make_pt(srt, scene, w, h, 8, True)
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 6):
         pt.set_kernel(mode)
         assert bits_equal(pt.render_epoch(8, 1, spp), want), f"kernel mode {mode}"
     for mode in (3, 5):
@@ -430,25 +439,75 @@ def test_full_size_properties(srt):
     ("cbox_refract", True, (32, 32), 3, 8),
 ])
 def test_wave_kernel_equals_general_kernel_and_oracle(srt, name, use_bvh, wh, spp, depth):
-    """The wave-uniform persistent kernel (mode 2), the same kernel with the flattened per-lane walk (mode 5) and
-    the general per-lane kernels (modes 1, 4) are independent device implementations of scene.hit; all must
-    reproduce the oracle's epoch image bit for bit."""
+    """The wave-uniform persistent kernel (mode 2), the same kernel with the flattened per-lane walk (mode 5), the
+    streamed form (mode 6: logic + ray-cast kernels) and the general per-lane kernels (modes 1, 4) are independent device
+    implementations of the epoch; all must reproduce the oracle's epoch image bit for bit."""
     scene = pt_scene(name)
     w, h = wh
     want = H.OraclePT(scene, w, h, depth, use_bvh).epoch(5, 9, spp)
     pt = make_pt(srt, scene, w, h, depth, use_bvh)
     rays = []
-    for mode in (1, 2, 4, 5):
+    for mode in (1, 2, 4, 5, 6):
         pt.set_kernel(mode)
         pt.ray_count(reset=True)
         img = pt.render_epoch(5, 9, spp)
         assert bits_equal(img, want), f"kernel mode {mode} differs from the oracle"
         rays.append(pt.ray_count()[0])
-    assert rays[0] == rays[1] == rays[2] == rays[3] > 0      # all kernels trace exactly the same rays
+    assert len(set(rays)) == 1 and rays[0] > 0               # all kernels trace exactly the same rays
     pt.set_kernel(2)
     pt.set_tiling(16, 8, 1, 3)         # sharded: rank 1 of 3
     part = np.full((h, w, 3), -1.0, np.float32)
     pt.render_epoch(5, 9, spp, out=part)
+    mask = part[..., 0] != -1.0
+    assert mask.any() and not mask.all() and bits_equal(part[mask], want[mask])
+    pt.close()
+
+
+def test_cfg5_large_mesh_every_kernel(srt):
+    """BASELINE configs[4] at size: the Cornell box with a 131 072-triangle glass mesh (80 127-node BVH<Triangle>, depth 18).
+    Per-sample radiance, RNG ledger, per-sample ray counts and the traversal counters against the oracle (4 k samples of
+    the 1024 x 1024 image), 2 k scene.hit records through the nested and the flattened walk, and one epoch image through
+    every kernel mode - the wave kernel's compacted BLAS walks with three- and two-ray batches (dead-ray elision), lane
+    per sample, lane per pixel, flattened walk, streamed wavefront - plus a shard of it.  The reference-built fixture of
+    the same scene is covered by test_hip_matches_reference_golden."""
+    scene = pt_scene("cbox_blob131072_glass")
+    w = h = 1024
+    pt = make_pt(srt, scene, w, h, 8, True)
+    o = H.OraclePT(scene, w, h, 8, True, math_mode=1)
+    xs, ys, ss = pt_sample_list(77, w, h, 4096, max_sample=1024)
+    cnt = np.zeros(8, np.uint64)
+    o_rgb, o_draws, o_rays = o.trace_samples(5, xs, ys, ss, cnt)
+    rgb, draws, rays = pt.trace_samples(5, xs, ys, ss)
+    assert bits_equal(rgb, o_rgb) and np.array_equal(draws, o_draws) and np.array_equal(rays, o_rays)
+    assert pt.counters() == dict(zip(H.COUNTER_NAMES, (int(v) for v in cnt)))
+    org, d, b = random_rays(78, 2048)
+    org = (org * np.float32(0.6) + np.array([0.05, 0.15, 0.1], np.float32)).astype(np.float32)   # most rays meet the mesh
+    want_hits = o.hit(org, d, b)
+    assert int(want_hits[:, 0].sum()) > 600
+    for mode in (0, 5):
+        pt.set_kernel(mode)
+        assert bits_equal(pt.hit(org, d, b), want_hits), f"scene.hit (kernel mode {mode}) differs from the oracle"
+    ew, eh, spp = 96, 64, 3
+    pt.set_params(ew, eh, spp, 8, True)
+    want = H.OraclePT(scene, ew, eh, 8, True).epoch(11, 2, spp)
+    counts = []
+    for mode in MESH_KERNEL_MODES:
+        pt.set_kernel(mode)
+        pt.ray_count(reset=True)
+        assert bits_equal(pt.render_epoch(11, 2, spp), want), f"kernel mode {mode} differs from the oracle on the large mesh"
+        counts.append(pt.ray_count()[0])
+    assert len(set(counts)) == 1 and counts[0] > 0
+    pt.set_elision(True)
+    for mode in MESH_ELISION_MODES:
+        pt.set_kernel(mode)
+        pt.ray_count(reset=True); pt.rays_elided(reset=True)
+        assert bits_equal(pt.render_epoch(11, 2, spp), want), f"kernel mode {mode} with elision differs from the oracle"
+        assert pt.ray_count()[0] == counts[0] and pt.rays_elided() > 0
+    pt.set_elision(False)
+    pt.set_kernel(0)
+    pt.set_tiling(32, 16, 2, 5)        # rank 2 of 5
+    part = np.full((eh, ew, 3), -1.0, np.float32)
+    pt.render_epoch(11, 2, spp, out=part)
     mask = part[..., 0] != -1.0
     assert mask.any() and not mask.all() and bits_equal(part[mask], want[mask])
     pt.close()
@@ -524,7 +583,7 @@ def test_random_scenes_all_kernels(srt):
             continue
         pt = make_pt(srt, scene, w, h, depth, use_bvh)
         rays = set()
-        for mode, elide in ((2, False), (2, True), (4, True), (1, False), (5, False)):
+        for mode, elide in ((2, False), (2, True), (4, True), (1, False), (5, False), (6, False), (6, True)):
             pt.set_kernel(mode)
             pt.set_elision(elide)
             pt.ray_count(reset=True)
@@ -552,7 +611,7 @@ def test_edge_shapes(srt, w, h, depth, spp, tile, world):
     scene = pt_scene("cbox")
     want = H.OraclePT(scene, w, h, depth, True).epoch(2**40 + 12345, 2**31 - 3, spp)   # large seed / sample base
     pt = make_pt(srt, scene, w, h, depth, True)
-    for mode in (2, 4, 5):
+    for mode in (2, 4, 5, 6):
         pt.set_kernel(mode)
         img = np.full((h, w, 3), -7.0, np.float32)
         for rank in range(world):

@@ -50,10 +50,7 @@ def test_oracle_matches_reference_golden(path, math_mode):
         assert bits_equal(boxes, g["tlas_boxes"]) and np.array_equal(links, g["tlas_links"])
         assert np.array_equal(order[: len(scene["objects"])], g["tlas_order"])
         for k in range(len(scene["objects"])):
-            if f"blas{k}_boxes" in g:
-                bb, bl, bo = o.dump_bvh(k)
-                assert bits_equal(bb, g[f"blas{k}_boxes"]) and np.array_equal(bl, g[f"blas{k}_links"])
-                assert np.array_equal(bo[: len(g[f"blas{k}_order"])], g[f"blas{k}_order"])
+            H.check_blas_against_golden(g, k, o.dump_bvh)
     if "epoch" in g:
         ew, eh, spp, base = (int(x) for x in g["epoch_meta"])
         o2 = H.OraclePT(scene, ew, eh, depth, use_bvh, math_mode=math_mode)
