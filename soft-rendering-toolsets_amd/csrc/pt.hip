@@ -263,7 +263,7 @@ struct srt_pt {
   // device copies
   Node* d_nodes = nullptr; Tri* d_tris = nullptr; TriNrm* d_nrm = nullptr; Object* d_objects = nullptr;
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
-  WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr;
+  WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr; uint32_t* d_wave_lazy = nullptr;
   DeltaLight* d_dlights = nullptr;
   std::vector<DeltaLight> delta_lights;   // srt_pt_add_light, in call order
   uint32_t env_type = 0; float env_radiance[3] = {0, 0, 0};   // srt_pt_set_env_light
@@ -285,11 +285,13 @@ struct srt_pt {
     uint32_t* d_ray_id = nullptr; size_t ray_id_n = 0;
     uint2* d_hits = nullptr; size_t hits_n = 0;
     StreamCounters* d_sc = nullptr;
+    unsigned long long* d_block_counters = nullptr; size_t block_counters_n = 0;
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
-  int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0;   // pt_cast_kernel's launch shape for the committed scene (0: not derived yet)
+  int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0; uint32_t cast_depth = 0;   // pt_cast_kernel's launch shape (0: not derived yet)
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
+  unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
   int elide = 0;                            // srt_pt_set_elision
   unsigned long long last_counters[C_COUNT] = {0};
@@ -348,7 +350,7 @@ DScene device_scene(const srt_pt* pt) {
   DScene S;
   S.nodes = pt->d_nodes; S.tris = pt->d_tris; S.tri_nrm = pt->d_nrm; S.objects = pt->d_objects;
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
-  S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas;
+  S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas; S.wave_lazy = pt->d_wave_lazy;
   S.delta_lights = pt->d_dlights; S.ndelta = (uint32_t)F.delta_lights.size();
   S.env_map = pt->d_env_map; S.env_w = pt->env_w; S.env_h = pt->env_h;
   S.env_type = pt->env_type; S.env_radiance[0] = pt->env_radiance[0]; S.env_radiance[1] = pt->env_radiance[1]; S.env_radiance[2] = pt->env_radiance[2];
@@ -419,8 +421,12 @@ int wave_trav(const srt_pt* pt) {
   if (m == 2) return sweeps_fit ? (blas ? 1 : 0) : -1;
   if (m == 3) return (sweeps_fit && !lights) ? (blas ? 1 : 0) : -1;
   if (m == 5) return (flat_fits && !lights) ? 2 : -1;
+  const bool sweeps_stream = sweeps_fit && blas && F.lazy_objects.size() <= kMaxLazy && stream_fits(F);
   if (m == 6) return stream_fits(F) ? 3 : -1;
-  // auto: scenes with a real BVH<Triangle> or with more objects than the sweeps take go through the streamed form
+  if (m == 7) return sweeps_stream ? 4 : -1;
+  // auto: a few objects, some of them meshes with a real BVH<Triangle> (BASELINE configs[4]): the sweeps stay, the walks of
+  // those meshes are queued (streamed sweeps); more objects than the sweeps take: every ray through the ray-cast kernel
+  if (sweeps_stream) return 4;
   if ((blas || !sweeps_fit) && stream_fits(F)) return 3;
   // auto: the sweeps whenever the scene has few enough objects.  Meshes with a real BVH<Triangle> are walked per lane
   // inside the sweeps, only by the rays that can reach them and compacted over the wave (object_testN): 407 / 771 / 1458
@@ -463,7 +469,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
   const int trav = wave_trav(pt);
-  if (trav == 3) return render_epoch_stream(pt, s, seed, sample_base, samples, d_tiles_out);
+  if (trav >= 3) return render_epoch_stream(pt, s, seed, sample_base, samples, d_tiles_out);
   const bool stamp = pt->kernel_mode == 3;
   const size_t nq = (F.use_bvh && trav != 2) ? F.wave_tlas.size() : 0;
   const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
@@ -553,13 +559,15 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   const TileMap& T = pt->tiles;
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const FlatScene& F = pt->built.flat;
+  const int trav = wave_trav(pt);                         // 3: every ray through the ray-cast kernel, 4: sweeps in the logic kernel, walks queued
   const bool dl = !F.delta_lights.empty() || pt->env_type != 0;
   const bool two = elision_provable(pt);
   const uint32_t burst = two ? 2u : kBurst;
+  const uint32_t nslots = trav == 4 ? (uint32_t)F.lazy_objects.size() * burst : burst;   // queue slots per path slot
   int st;
   // the cast kernel's launch shape: frames per lane from the scene's tree depths, as many waves per CU as the LDS holds
-  const uint32_t depth = F.max_tlas_depth + F.max_blas_depth + 1u;
-  if (pt->cast_blocks == 0) {
+  const uint32_t depth = (trav == 4 ? 0u : F.max_tlas_depth) + F.max_blas_depth + 1u;
+  if (pt->cast_blocks == 0 || pt->cast_depth != depth) {
     int cus = 0;
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
     const size_t per_wave = (size_t)depth * 3u * 64u * sizeof(uint32_t);
@@ -567,22 +575,37 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     for (int w : {4, 2, 1}) {
       const size_t lds = per_wave * (size_t)w;
       if (lds > 160u * 1024u) continue;
-      if (hipFuncSetAttribute((const void*)pt_cast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+      if (hipFuncSetAttribute((const void*)pt_cast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pt_cast_kernel, 64 * w, lds) != hipSuccess || per_cu < 1) continue;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pt_cast_kernel<false>, 64 * w, lds) != hipSuccess || per_cu < 1) continue;
       if (per_cu * w > best_waves) { best_waves = per_cu * w; pt->cast_threads = 64 * w; pt->cast_blocks = per_cu * cus; pt->cast_lds = lds; }
     }
     if (best_waves == 0) return srt::fail(SRT_ERR_UNSUPPORTED, "the ray-cast kernel's traversal stack (%u frames per lane) does not fit into LDS", depth);
-    SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
+    pt->cast_depth = depth;
+    SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
+    if (getenv("SRT_CAST_STATS") && !pt->d_cast_stats) {
+      SRT_HIP(hipMalloc(&pt->d_cast_stats, CS_COUNT * sizeof(unsigned long long)));
+      SRT_HIP(hipMemset(pt->d_cast_stats, 0, CS_COUNT * sizeof(unsigned long long)));
+    }
+    if (pt->d_cast_stats) SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u frames per lane), %d waves/CU\n",
                                      pt->cast_blocks, pt->cast_threads, pt->cast_lds, depth, best_waves);
   }
+  // the logic kernel: 1024-thread blocks; the streamed sweeps keep their per-wave slots in LDS (16 waves)
+  const size_t nq = (trav == 4 && F.use_bvh) ? F.wave_tlas.size() : 0;
+  const size_t lds_per_wave = (size_t)(nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);
+  uint32_t lthreads = kStreamBlock;                       // fewer waves per block when a larger top-level tree needs more slots
+  while (lthreads > 256u && (lthreads / 64u) * lds_per_wave > 150u * 1024u) lthreads /= 2u;
+  const size_t logic_lds = (size_t)(lthreads / 64u) * lds_per_wave;
+  const void* lkern = trav == 4 ? (two ? (const void*)pt_wave_kernel<false, 4, false, 2> : dl ? (const void*)pt_wave_kernel<false, 4, true, 3> : (const void*)pt_wave_kernel<false, 4, false, 3>)
+                                : (two ? (const void*)pt_wave_kernel<false, 3, false, 2> : dl ? (const void*)pt_wave_kernel<false, 3, true, 3> : (const void*)pt_wave_kernel<false, 3, false, 3>);
+  if (logic_lds > 160u * 1024u) return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed sweeps' LDS slots (%zu bytes) do not fit", logic_lds);
+  SRT_HIP(hipFuncSetAttribute(lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)logic_lds));
   const uint32_t chunk = samples_per_launch(px);
   srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
   if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   if (!B.d_sc) SRT_HIP(hipMalloc(&B.d_sc, sizeof(StreamCounters)));
-  const uint32_t state_words = dl ? (uint32_t)SW_DL_WORDS : (uint32_t)SW_BASE_WORDS;
   const uint32_t shadow_batches = (uint32_t)((F.delta_lights.size() + 2) / 3);
   const DScene DS = device_scene(pt);
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
@@ -595,46 +618,60 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     P.total_units = px * (P.groups3 + P.singles);
     // path slots: every unit its own while they are few, else a fixed population that is refilled from the unit queue
     uint32_t want_slots = pt->stream_slots ? pt->stream_slots : (getenv("SRT_STREAM_SLOTS") ? (uint32_t)atoi(getenv("SRT_STREAM_SLOTS")) : (1u << 20));
-    if (want_slots < 256u) want_slots = 256u;
-    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(((uint64_t)P.total_units + 255u) / 256u * 256u, (want_slots + 255u) / 256u * 256u);
+    if (want_slots < lthreads) want_slots = lthreads;
+    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(((uint64_t)P.total_units + lthreads - 1) / lthreads * lthreads,
+                                                         (want_slots + lthreads - 1) / lthreads * lthreads);
     if (n && nlanes) {
       P.nlanes = nlanes;
+      const uint32_t nblocks = nlanes / lthreads;
       if ((st = ensure(&B.d_records, &B.records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
       if ((st = ensure(&B.d_state, &B.state_words, (size_t)nlanes * SW_DL_WORDS)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_ray_o, &B.ray_o_n, (size_t)nlanes * 3)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_ray_d, &B.ray_d_n, (size_t)nlanes * 3)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_ray_id, &B.ray_id_n, (size_t)nlanes * 3)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_hits, &B.hits_n, (size_t)nlanes * 3)) != SRT_OK) return st;
-      (void)state_words;
+      if ((st = ensure(&B.d_ray_o, &B.ray_o_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_d, &B.ray_d_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_id, &B.ray_id_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_hits, &B.hits_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if (B.block_counters_n < 2 * (size_t)nblocks) {
+        if ((st = ensure(&B.d_block_counters, &B.block_counters_n, 2 * (size_t)nblocks)) != SRT_OK) return st;
+        SRT_HIP(hipMemsetAsync(B.d_block_counters, 0, 2 * (size_t)nblocks * sizeof(unsigned long long), s));
+      }
       P.sample_out = B.d_samples; P.records = B.d_records; P.npix = px; P.chunk = kChunk;
       P.queue_head = &B.d_sc->queue_head; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1;
       P.stamps = nullptr; P.flat_ready = 0; P.flat_interior = 0;
-      P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_d; P.ray_id = B.d_ray_id; P.hits = B.d_hits; P.sc = B.d_sc;
+      P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_d; P.hits = B.d_hits; P.sc = B.d_sc;
+      P.block_counters = B.d_block_counters;
       P.obj_shift = stream_obj_shift(F);
       SRT_HIP(hipMemsetAsync(B.d_sc, 0, sizeof(StreamCounters), s));
-      SRT_HIP(hipMemsetAsync(B.d_state, 0, (size_t)nlanes * sizeof(uint32_t), s));   // the flags plane: every slot idle
+      SRT_HIP(hipMemsetAsync(B.d_state, 0, 2 * (size_t)nlanes * sizeof(uint32_t), s));   // the flags and emit planes: every slot idle
       // generations: list scheduling of units of <= M batches on nlanes slots
       const uint64_t M = 1ull + (uint64_t)burst * pt->max_depth * (1ull + (dl ? shadow_batches : 0ull));
       const uint64_t gens = ((uint64_t)P.total_units * M + nlanes - 1) / nlanes + M + 2;
       CastParams C{};
       C.ray_o = B.d_ray_o; C.ray_d = B.d_ray_d; C.ray_id = B.d_ray_id; C.hits = B.d_hits; C.nlanes = nlanes;
-      C.depth = depth; C.obj_shift = P.obj_shift;
+      C.depth = depth; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
+      C.walk_nr = trav == 4 ? burst : 0u;
+      for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];
       C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 16u;
       C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
       if (C.fetch_min < 1u) C.fetch_min = 1u;
-      const dim3 lgrid(nlanes / 256u), lblock(256);
+      C.stats = pt->d_cast_stats;
+      const dim3 lgrid(nblocks), lblock(lthreads);
+      const dim3 cgrid((nlanes + kCompactChunk - 1) / kCompactChunk);
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
       for (uint64_t g = 0; g < gens; g++) {
         P.gen = (uint32_t)g;
-#define SRT_LAUNCH_LOGIC(DL_, NR_)                                                                                               \
-  pt_wave_kernel<false, 3, DL_, NR_><<<lgrid, lblock, 0, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes, DS.lights,         \
-                                                                DS.light_tris, DS.materials, DS.wave_tlas, DS.blas_recs, P.records, \
-                                                                P.sample_out)
-        if (two) SRT_LAUNCH_LOGIC(false, 2); else if (dl) SRT_LAUNCH_LOGIC(true, 3); else SRT_LAUNCH_LOGIC(false, 3);
+#define SRT_LAUNCH_LOGIC(TRAV_, DL_, NR_)                                                                                          \
+  pt_wave_kernel<false, TRAV_, DL_, NR_><<<lgrid, lblock, logic_lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes,         \
+                                                                          DS.lights, DS.light_tris, DS.materials, DS.wave_tlas,    \
+                                                                          DS.blas_recs, P.records, P.sample_out)
+        if (trav == 4) { if (two) SRT_LAUNCH_LOGIC(4, false, 2); else if (dl) SRT_LAUNCH_LOGIC(4, true, 3); else SRT_LAUNCH_LOGIC(4, false, 3); }
+        else { if (two) SRT_LAUNCH_LOGIC(3, false, 2); else if (dl) SRT_LAUNCH_LOGIC(3, true, 3); else SRT_LAUNCH_LOGIC(3, false, 3); }
 #undef SRT_LAUNCH_LOGIC
-        C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1];
-        pt_cast_kernel<<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
+        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id);
+        C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
+        if (pt->d_cast_stats) pt_cast_kernel<true><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
+        else pt_cast_kernel<false><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
       }
+      pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
@@ -708,13 +745,21 @@ int srt_pt_destroy(srt_pt* pt) {
   if (pt->device >= 0) {
     (void)hipSetDevice(pt->device);
     (void)hipStreamSynchronize(pt->stream);
+    if (pt->d_cast_stats) {                               // SRT_CAST_STATS=1 (diagnostic): the sums, on stderr
+      unsigned long long h[CS_COUNT];
+      static const char* names[CS_COUNT] = {"outer", "fetch", "interior_trips", "interior_lanes", "leaf_trips", "leaf_lanes", "leaf_tris",
+                                            "object_trips", "object_lanes", "pop_trips", "pop_lanes", "walking_lanes"};
+      if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, pt->d_cast_stats, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+        for (int i = 0; i < CS_COUNT; i++) fprintf(stderr, "[srt] cast %s %llu\n", names[i], h[i]);
+      (void)hipFree(pt->d_cast_stats);
+    }
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
-    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
+    (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_wave_lazy); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     for (auto& kv : pt->epoch_buffers) {
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
       (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id);
-      (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc);
+      (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc); (void)hipFree(kv.second.d_block_counters);
     }
     for (auto& v : {&pt->timed, &pt->spare})
       for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -847,7 +892,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
     if ((st = upload(&pt->d_nodes, F.nodes)) || (st = upload(&pt->d_tris, F.tris)) || (st = upload(&pt->d_nrm, F.tri_nrm)) ||
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
         (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
-        (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)) ||
+        (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)) || (st = upload(&pt->d_wave_lazy, F.wave_lazy)) ||
         (st = upload(&pt->d_dlights, F.delta_lights)) || (st = upload(&pt->d_env_map, pt->env_map)))
       return st;
   }
@@ -893,8 +938,8 @@ int srt_pt_tile_info(srt_pt* pt, uint32_t* local_tiles, uint32_t* tiles_per_rank
 
 int srt_pt_set_kernel(srt_pt* pt, int mode) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_kernel: NULL context");
-  if (mode < 0 || mode > 6)
-    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped), 4 (per-lane, lane per sample), 5 (persistent waves, flattened per-lane walk) or 6 (streamed: logic + ray-cast kernels)");
+  if (mode < 0 || mode > 7)
+    return srt::fail(SRT_ERR_INVALID, "kernel mode must be 0 (auto), 1 (per-lane, lane per pixel), 2 (wave-uniform), 3 (wave-uniform, stamped), 4 (per-lane, lane per sample), 5 (persistent waves, flattened per-lane walk), 6 (streamed: logic + ray-cast kernels) or 7 (streamed sweeps: BVH<Triangle> walks queued)");
   pt->kernel_mode = mode;
   return SRT_OK;
 }
@@ -914,6 +959,9 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
                        pt->built.flat.objects.size());
     if (pt->kernel_mode == 5 && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "the flattened-walk kernel needs 1..31 objects (scene has %zu)", pt->built.flat.objects.size());
+    if (pt->kernel_mode == 7 && !wave_kernel_applies(pt))
+      return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed sweeps need 1..%u objects, of which 1..%u meshes with a real BVH<Triangle> (scene has %zu objects, %zu such meshes)",
+                       kWaveMaxObjects, kMaxLazy, pt->built.flat.objects.size(), pt->built.flat.lazy_objects.size());
     if (pt->kernel_mode == 6 && !wave_kernel_applies(pt))
       return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed form cannot pack this scene's hits (%zu objects, %zu triangles)", pt->built.flat.objects.size(),
                        pt->built.flat.tris.size());

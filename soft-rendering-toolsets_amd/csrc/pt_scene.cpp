@@ -411,7 +411,27 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
         append_triangles(in.mesh, nullptr);
       }
     }
+    if (o.kind == OBJ_MESH && o.use_bvh != 0u && o.nrec > 0u) {
+      // a mesh with a real BVH<Triangle>: its ordinal among those (the streamed sweeps queue its walks per ordinal)
+      o.use_bvh |= (uint32_t)F.lazy_objects.size() << 8;
+      F.lazy_objects.push_back(slot);
+    }
     F.objects.push_back(o);
+  }
+
+  // Which children of the top-level records hold a mesh with a real BVH<Triangle> somewhere below (children come after
+  // their parent in sweep order, so one backward pass does it).
+  F.wave_lazy.assign(F.wave_tlas.size(), 0u);
+  for (size_t q = F.wave_tlas.size(); q-- > 0;) {
+    const WaveInterior& w = F.wave_tlas[q];
+    auto child_has = [&](int32_t ref, uint32_t cnt) {
+      if (ref >= 0) return F.wave_lazy[(size_t)ref] != 0u;
+      const uint32_t first = (uint32_t)~ref;
+      for (uint32_t k = first; k < first + cnt && k < F.objects.size(); k++)
+        if (F.objects[k].kind == OBJ_MESH && F.objects[k].use_bvh != 0u && F.objects[k].nrec > 0u) return true;
+      return false;
+    };
+    F.wave_lazy[q] = (child_has(w.l_ref, w.l_cnt) ? 1u : 0u) | (child_has(w.r_ref, w.r_cnt) ? 2u : 0u);
   }
 
   // Area lights: List<Object> of Tri_Mesh(mesh, false) in insertion order (rays/pathtracer.cpp:105-116,163).

@@ -43,7 +43,7 @@ enum : uint32_t { OBJ_MESH = 0, OBJ_SPHERE = 1 };
 struct Object {
   uint32_t kind, has_trans;
   int32_t material;
-  uint32_t use_bvh;
+  uint32_t use_bvh;            // bit 0: the mesh was built with a BVH<Triangle>; bits 8..: ordinal among the meshes with nrec > 0
   uint32_t node_base, nnodes;  // BLAS nodes [node_base, node_base + nnodes)
   uint32_t tri_base, ntri;     // triangles [tri_base, tri_base + ntri)
   float radius;
@@ -115,6 +115,8 @@ struct FlatScene {
   // Per-mesh BVH<Triangle> as interior records (both child boxes in one 64-byte fetch).  Child refs: >= 0 interior
   // rank inside the mesh's range; < 0 leaf, ~ref = (first triangle slot << 3) | triangle count (<= 4).
   std::vector<WaveInterior> blas_recs;
+  std::vector<uint32_t> lazy_objects;               // object slots whose mesh has a real BVH<Triangle> (nrec > 0), by ordinal
+  std::vector<uint32_t> wave_lazy;                  // per wave_tlas record: bit 0 / 1 = the left / right child's subtree holds such a mesh
 };
 
 // Input side (what the C ABI collects between scene_begin and scene_commit).

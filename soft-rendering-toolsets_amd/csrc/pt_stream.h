@@ -30,14 +30,16 @@ namespace srt {
 // Device words shared by the kernels of one streamed launch (zeroed before generation 0).
 struct StreamCounters {
   unsigned long long queue_head;   // next work unit (refill)
-  unsigned long long units_done;   // units whose last sample has been stored (or that lie outside the image)
-  uint32_t nrays[2];               // rays appended by logic generation g: [g & 1]
-  uint32_t cast_head[2];           // next ray of generation g to hand to a cast wave: [g & 1]
+  uint32_t nrays[2];               // entries of generation g's dense ray list: [g & 1]
+  uint32_t cast_head[2];           // next entry of generation g to hand to a cast wave: [g & 1]
+  uint32_t alive[2];               // generation g left at least one slot alive: [g & 1]
+  uint32_t done;                   // set once a generation left no slot alive and the unit queue is drained
+  uint32_t pad;
 };
 
 // Words of a path slot's saved state (planes of `nlanes` words).  The DL build appends its shadow-phase state.
 enum {
-  SW_FLAGS = 0, SW_PX, SW_PY, SW_SAMPLES, SW_PIXEL_SLOT, SW_PEND0, SW_PEND1, SW_RNG_LO, SW_RNG_HI, SW_ORG, SW_DC = SW_ORG + 3,
+  SW_FLAGS = 0, SW_EMIT, SW_PX, SW_PY, SW_SAMPLES, SW_PIXEL_SLOT, SW_PEND0, SW_PEND1, SW_RNG_LO, SW_RNG_HI, SW_ORG, SW_DC = SW_ORG + 3,
   SW_CB0 = SW_DC + 3, SW_CB1, SW_ATT, SW_PDF4 = SW_ATT + 3, SW_PDF_AREA, SW_BASE_WORDS,
   // DL only
   SW_D0 = SW_BASE_WORDS, SW_D1 = SW_D0 + 3, SW_LIGHT_I = SW_D1 + 3, SW_HELD, SW_PL, SW_DA = SW_PL + 3, SW_D6 = SW_DA + 3,
@@ -68,24 +70,123 @@ struct LdsStack {
 };
 
 struct CastParams {
-  const float4* ray_o;       // [ray] origin, dist_bounds.x
-  const float4* ray_d;       // [ray] direction, dist_bounds.y
-  const uint32_t* ray_id;    // [ray] path slot * 4 + batch slot
-  uint2* hits;               // [batch slot * nlanes + path slot] {distance bits, object << obj_shift | triangle, or 0xFFFFFFFF}
+  const float4* ray_o;       // [queue slot * nlanes + path slot] origin, dist_bounds.x
+  const float4* ray_d;       // [same] direction, dist_bounds.y
+  const uint32_t* ray_id;    // dense list of the positions that carry a ray this generation (pt_compact_kernel)
+  uint2* hits;               // [same position] {distance bits, object << obj_shift | triangle, or 0xFFFFFFFF}
   uint32_t nlanes;
+  uint32_t walk_nr;          // 0: the entries are world rays (scene.hit).  NR > 0: they are walk requests of the streamed sweeps -
+                             // object-space rays for the BVH<Triangle> of mesh ordinal position / nlanes / NR; the result is
+                             // {world distance, triangle}
+  uint32_t lazy_obj[4];      // object slot of mesh ordinal m
+  StreamCounters* sc;
+  uint32_t total_units;
+  uint32_t gen;
   const uint32_t* nrays;     // rays of this generation
   uint32_t* head;            // queue head of this generation
   uint32_t depth;            // frames per lane
   uint32_t fetch_min;        // idle lanes of a wave that trigger a fetch
   uint32_t interior_min;     // lanes at interior records that keep the wave in the interior-step loop
   uint32_t obj_shift;
+  unsigned long long* stats;   // STATS build only: CS_* sums over all waves
 };
 
-// scene.hit for a queue of rays (see the head comment).
+// Dense list of the queue positions that carry a ray: the logic kernel left one mask word per path slot (bit q: queue slot
+// q); a block takes kCompactChunk consecutive path slots and appends its positions with ONE atomic.
+constexpr uint32_t kCompactChunk = 8192;
+__global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __restrict__ emit, uint32_t nlanes, uint32_t nslots,
+                                                          StreamCounters* sc, uint32_t gen, uint32_t* __restrict__ ray_id) {
+  if (sc->done != 0u) return;
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * kCompactChunk;
+  constexpr uint32_t kPer = kCompactChunk / 1024u;
+  uint32_t m[kPer], n = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; k++) {
+    const uint32_t slot = first + k * 1024u + threadIdx.x;
+    m[k] = slot < nlanes ? emit[slot] : 0u;
+    if (m[k] & 0x80000000u) sc->alive[gen & 1u] = 1u;     // (every writer stores the same value)
+    m[k] &= 0x7fffffffu;
+    n += (uint32_t)__popc(m[k]);
+  }
+  uint32_t incl = n;                                      // inclusive scan over the wave, then over the block's waves
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += v; }
+  if (lane == 63u) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+    s_base = total ? atomicAdd(&sc->nrays[gen & 1u], total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = s_base + s_wave[wave] + incl - n;
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; k++) {
+    const uint32_t slot = first + k * 1024u + threadIdx.x;
+    uint32_t bits = m[k];
+    while (bits) {
+      const uint32_t q = (uint32_t)__ffs((int)bits) - 1u;
+      bits &= bits - 1u;
+      ray_id[at++] = q * nlanes + slot;
+    }
+  }
+  (void)nslots;
+}
+
+// After the last generation: the logic blocks' ray counts into the context's totals {rays, rays elided}.
+__global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_counters, uint32_t nblocks, unsigned long long* __restrict__ totals) {
+  unsigned long long a = 0, b = 0;
+  for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    a += block_counters[2 * (size_t)i]; b += block_counters[2 * (size_t)i + 1];
+    block_counters[2 * (size_t)i] = 0; block_counters[2 * (size_t)i + 1] = 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if ((threadIdx.x & 63u) == 0u) { if (a) atomicAdd(&totals[0], a); if (b) atomicAdd(&totals[1], b); }
+}
+
+// STATS build (diagnostic, SRT_CAST_STATS=1): how the waves spend their loop trips.
+enum { CS_OUTER = 0, CS_FETCH, CS_INTERIOR_TRIPS, CS_INTERIOR_LANES, CS_LEAF_TRIPS, CS_LEAF_LANES, CS_LEAF_TRIS, CS_OBJECT_TRIPS, CS_OBJECT_LANES,
+       CS_POP_TRIPS, CS_POP_LANES, CS_WALKING_LANES, CS_COUNT };
+
+// Brings a lane that has just taken a step to a state one of the three phases below picks up: frames are unwound on
+// the spot (a few LDS words each), a BVH<Object> leaf becomes "its objects next", the end of a mesh's tree becomes
+// "finish Object::hit" (object phase), the end of the top-level tree finishes the ray.
+template <typename StackT>
+SRT_DEV void cast_settle(FlatState& F, const StackT& stack) {
+  for (;;) {
+    if (F.mode == FM_UNWIND) {
+      if (flat_plain_frame(F)) { flat_pop(F, stack); continue; }
+      if (F.level) { F.mode = FM_OBJECT; return; }
+      F.res0 = F.ret; F.mode = FM_DONE;
+      return;
+    }
+    if (F.mode == FM_NODE && F.cur < 0 && F.level == 0u) {
+      const uint32_t packed = (uint32_t)~F.cur;
+      F.obj_i = packed >> 3; F.obj_end = F.obj_i + (packed & 7u);
+      F.acc = flat_no_hit();
+      F.mode = FM_OBJECT;
+    }
+    return;
+  }
+}
+
+// scene.hit for a queue of rays (see the head comment).  Every trip of the loop the wave runs ONE of three phases for the
+// lanes that stand there - interior records (cheap, by far the most frequent), Object::hit (ray -> object space, sphere /
+// one-leaf mesh on the spot, or into / out of a mesh's tree), a BVH<Triangle> leaf's triangles - and the others wait:
+// interior steps as long as enough lanes take part, else the fuller of the two expensive phases, so that those run with
+// the lanes that have piled up in front of them instead of with whoever happens to be there.
+template <bool STATS>
 __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
   const uint32_t nrays = *P.nrays;
-  if (nrays == 0u) return;
+  if (nrays == 0u) {
+    // nothing to cast.  If no slot is alive either and the unit queue is drained, the launch is finished.
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.sc->alive[P.gen & 1u] == 0u && P.sc->queue_head >= (unsigned long long)P.total_units) P.sc->done = 1u;
+    return;
+  }
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   const LdsStack stack{cast_lds + (size_t)wave * P.depth * 3u * 64u + (uint32_t)lane};
   FlatState F;                                            // F.mode == FM_DONE: the lane is idle
@@ -94,16 +195,28 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
   uint32_t my_id = 0;
   V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1);                  // the world ray (restored when the lane leaves a mesh)
   float wb0 = 0.0f, wb1 = 0.0f;
+  unsigned long long cs[CS_COUNT];
+  if (STATS)
+    for (int i = 0; i < CS_COUNT; i++) cs[i] = 0;
+#define CAST_STAT(i, v) if (STATS) cs[i] += (v)
   for (;;) {
+    const bool at_int = F.mode == FM_NODE && F.cur >= 0;
+    const bool at_leaf = F.mode == FM_NODE && F.cur < 0;   // (a BVH<Triangle> leaf: cast_settle has turned the others into objects)
+    const bool at_obj = F.mode == FM_OBJECT;
     const unsigned long long idle = __ballot(F.mode == FM_DONE);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (nidle >= P.fetch_min || nidle == 64u) {
+    const uint32_t n_int = (uint32_t)__popcll(__ballot(at_int)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf)),
+                   n_obj = (uint32_t)__popcll(__ballot(at_obj));
+    CAST_STAT(CS_OUTER, 1); CAST_STAT(CS_WALKING_LANES, 64u - nidle);
+    if (nidle == 64u || (!exhausted && nidle >= P.fetch_min)) {
+      CAST_STAT(CS_FETCH, 1);
       if (have && F.mode == FM_DONE) {                    // results out: every idle lane at once
         const Hit h = F.res0;
         uint2 o;
         o.x = __float_as_uint(h.hit ? h.dist : 0.0f);
         o.y = h.hit ? ((h.obj << P.obj_shift) | h.tri) : 0xFFFFFFFFu;
-        P.hits[(size_t)(my_id & 3u) * P.nlanes + (my_id >> 2)] = o;
+        if (P.walk_nr) o.y = h.hit ? h.tri : 0xFFFFFFFFu;
+        P.hits[my_id] = o;
         have = false;
       }
       if (!exhausted) {                                   // new rays in: one atomic per wave
@@ -113,36 +226,65 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const uint32_t idx = start + rank;
         if (F.mode == FM_DONE && idx < nrays) {
-          const float4 ro = P.ray_o[idx], rd = P.ray_d[idx];
           my_id = P.ray_id[idx];
+          const float4 ro = P.ray_o[my_id], rd = P.ray_d[my_id];
           wo = v3(ro.x, ro.y, ro.z); wd = v3(rd.x, rd.y, rd.z); wb0 = ro.w; wb1 = rd.w;
-          flat_begin(F, S, wo, wd, wd, wd, wb0, wb1, true, false, false);
+          if (P.walk_nr) {
+            // a walk request: the lane starts inside the mesh's tree, as flat_object leaves it there (Tri_Mesh::hit ->
+            // BVH<Triangle>::hit with times = dist_bounds / dir.norm()); when the tree is done the object phase finishes
+            // Object::hit (world distance) into F.acc, which is the result
+            const uint32_t m = my_id / P.nlanes / P.walk_nr;
+            const uint32_t slot = m == 0u ? P.lazy_obj[0] : (m == 1u ? P.lazy_obj[1] : (m == 2u ? P.lazy_obj[2] : P.lazy_obj[3]));
+            const Object& o = S.objects[slot];
+            F.res0 = flat_no_hit(); F.ret = F.res0; F.acc = F.res0;
+            F.act1 = false; F.act2 = false; F.r = 0u;
+            F.co = wo; F.cd = wd; F.b0 = wb0; F.b1 = wb1;
+            F.cinv = v3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+            const float dn = norm(wd);
+            F.tx = wb0 / dn; F.ty = wb1 / dn;
+            F.level = 1; F.rec_base = o.rec_base; F.tri_base = o.tri_base; F.xf = o.has_trans != 0u;
+            F.obj_i = slot; F.obj_end = slot + 1u;
+            F.sp = 0; F.base_sp = 0; F.cur = 0;
+            F.mode = FM_NODE;
+          } else {
+            flat_begin(F, S, wo, wd, wd, wd, wb0, wb1, true, false, false);
+          }
           have = true;
         }
         if (start + nidle >= nrays) exhausted = true;
       }
-      if (__ballot(F.mode != FM_DONE) == 0ull) {
-        if (exhausted) break;
-        continue;
-      }
+      if (__ballot(F.mode != FM_DONE) == 0ull && exhausted) break;
+      continue;
     }
-    // interior records: the bulk of the work and uniform in cost - repeated while enough lanes take part
-    for (;;) {
-      const bool can = F.mode == FM_NODE && F.cur >= 0;
-      if (__ballot(can) == 0ull) break;
-      if (can) {
+    if (n_int >= P.interior_min || (n_int != 0u && n_int >= n_obj && n_int >= n_leaf)) {
+      CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_int);
+      if (at_int) {
         flat_interior(F, stack, S);
-        while (F.mode == FM_UNWIND && flat_plain_frame(F)) flat_pop(F, stack);   // a double miss: straight back to a node
+        cast_settle(F, stack);
       }
-      if ((uint32_t)__popcll(__ballot(F.mode == FM_NODE && F.cur >= 0)) < P.interior_min) break;
-    }
-    if (F.mode == FM_NODE && F.cur < 0) flat_leaf(F, S);
-    if (F.mode == FM_OBJECT) flat_object(F, S);
-    while (F.mode == FM_UNWIND) {
-      if (flat_plain_frame(F)) flat_pop(F, stack);
-      else flat_exit(F, S, wo, wd, wd, wd, wb0, wb1);
+    } else if (n_obj != 0u && n_obj >= n_leaf) {
+      CAST_STAT(CS_OBJECT_TRIPS, 1); CAST_STAT(CS_OBJECT_LANES, n_obj);
+      if (at_obj) {
+        if (F.level) flat_exit(F, S, wo, wd, wd, wd, wb0, wb1);   // back from a mesh's tree: finish its Object::hit
+        else if (F.obj_i < F.obj_end) flat_object(F, S);          // the next object of the leaf / list
+        if (F.mode == FM_OBJECT && F.obj_i >= F.obj_end) { F.ret = F.acc; F.mode = FM_UNWIND; }
+        cast_settle(F, stack);
+      }
+    } else {
+      if (STATS) {
+        unsigned long long t = at_leaf ? (((uint32_t)~F.cur) & 7u) : 0u;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        cs[CS_LEAF_TRIPS]++; cs[CS_LEAF_LANES] += n_leaf; cs[CS_LEAF_TRIS] += __shfl(t, 0);
+      }
+      if (at_leaf) {
+        flat_leaf(F, S);
+        cast_settle(F, stack);
+      }
     }
   }
+#undef CAST_STAT
+  if (STATS && lane == 0)
+    for (int i = 0; i < CS_COUNT; i++) atomicAdd(&P.stats[i], cs[i]);
 }
 
 }  // namespace srt

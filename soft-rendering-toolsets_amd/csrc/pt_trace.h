@@ -24,6 +24,7 @@ struct DScene {
   const Material* materials;
   const WaveInterior* wave_tlas;   // interior nodes of the top-level tree in sweep order (pt_wave.h)
   const WaveInterior* blas_recs;   // interior records of every BVH<Triangle>
+  const uint32_t* wave_lazy;       // per wave_tlas record: which children hold a mesh with a real BVH<Triangle> (pt_scene.h)
   const DeltaLight* delta_lights;  // Pathtracer::point_lights
   uint32_t ndelta;
   uint32_t env_type;               // Pathtracer::env_light: 0 none, 1 Env_Sphere, 2 Env_Hemisphere (uniform radiance), 3 Env_Map

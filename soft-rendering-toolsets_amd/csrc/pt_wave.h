@@ -72,14 +72,17 @@ struct WaveParams {
   uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
   // TRAV 3 (streamed form, pt_stream.h): one invocation = one generation; nlanes = path slots
   uint32_t* state;           // [word][slot] saved path state
-  float4* ray_o;             // ray queue of this generation (NR * nlanes entries)
-  float4* ray_d;
-  uint32_t* ray_id;
-  const uint2* hits;         // [batch slot][path slot] results of the previous generation's rays
+  float4* ray_o;             // rays / walk requests of this generation at FIXED positions: [queue slot][path slot]
+  float4* ray_d;             //   TRAV 3: queue slot = batch slot; TRAV 4: queue slot = mesh ordinal * NR + batch slot
+  const uint2* hits;         // [queue slot][path slot] results of the previous generation's rays / walks
   StreamCounters* sc;
+  unsigned long long* block_counters;   // [block][2]: rays counted / rays elided by that block of the logic kernel, all generations
   uint32_t gen;              // generation number
   uint32_t obj_shift;        // packed hit = object slot << obj_shift | triangle
 };
+
+constexpr uint32_t kStreamBlock = 1024;   // threads per block of the streamed logic kernels (one atomic per block and counter)
+constexpr uint32_t kMaxLazy = 4;          // TRAV 4: meshes with a real BVH<Triangle> whose walks are queued
 
 // Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
 // (integer-division reciprocals, int->float conversions, matrix * constant products) can no longer be hoisted out
@@ -177,9 +180,13 @@ SRT_DEV Hit no_hit() { Hit h; h.hit = false; h.dist = 0.0f; h.obj = 0; h.tri = 0
 // world distance Trace::transform recomputes, and the winning triangle (global index).
 // HAS_BLAS = false compiles the per-lane BVH<Triangle> walk out (the host picks that build when every mesh is a
 // single leaf, e.g. the Cornell box): the walk's registers would otherwise halve the occupancy of the common path.
-template <bool HAS_BLAS, int NR>
+// QUEUE (TRAV 4, the streamed sweeps): the walk of a real BVH<Triangle> is not done here.  In the probe pass (emit) the rays
+// that need it are written - in the mesh's object space - to their fixed queue positions and flagged in emit_mask; the
+// ray-cast kernel walks them between two generations; the complete pass reads {world distance, triangle} back.
+template <bool HAS_BLAS, int NR, bool QUEUE = false>
 SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1,
-                          Counters& cnt, bool* hit, float* dist, uint32_t* tri, const bool* need, uint32_t* cidx) {
+                          Counters& cnt, bool* hit, float* dist, uint32_t* tri, const bool* need, uint32_t* cidx,
+                          const WaveParams* QP = nullptr, uint32_t lane_global = 0, bool emit = false, uint32_t* emit_mask = nullptr) {
   const Object& o = S.objects[k];
   const bool xf = o.has_trans != 0;
   V3 oorg = org;
@@ -223,7 +230,27 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
     sqrtN<NR>(n2, miss, nr);
 #pragma unroll
     for (int r = 0; r < NR; r++) dist[r] = fabsf(nr[r]);
-  } else if (HAS_BLAS && o.use_bvh && o.nrec > 0) {
+  } else if (HAS_BLAS && QUEUE && o.use_bvh && o.nrec > 0) {
+    const uint32_t m = o.use_bvh >> 8;                   // ordinal of this mesh (pt_scene.h)
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      hit[r] = false; dist[r] = 0.0f; tri[r] = 0u;
+      if (need[r]) {
+        const size_t pos = (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP->nlanes + lane_global;
+        if (emit) {
+          QP->ray_o[pos] = make_float4(oorg.x, oorg.y, oorg.z, ob0[r]);
+          QP->ray_d[pos] = make_float4(od[r].x, od[r].y, od[r].z, ob1[r]);
+          *emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
+        } else {
+          const uint2 hv = QP->hits[pos];
+          hit[r] = hv.y != 0xFFFFFFFFu;
+          dist[r] = hit[r] ? __uint_as_float(hv.x) : 0.0f;
+          tri[r] = hit[r] ? hv.y : 0u;
+        }
+      }
+    }
+    return;                                              // world distances are final
+  } else if (HAS_BLAS && !QUEUE && o.use_bvh && o.nrec > 0) {
     // A real BVH<Triangle>: a per-lane walk, the expensive leaf.  Only the rays whose traversal can reach this object
     // (need[], from the caller) are walked, and they are compacted over the wave first: the (lane, slot) pairs get
     // consecutive item numbers (ballot prefix), each lane then walks item `round * 64 + lane` - fetched from its owner
@@ -346,17 +373,19 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC3T
 #define SRT_WAVE_OCC3T 4
 #endif
-__global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WAVE_OCC2) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC)) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+__global__ __launch_bounds__(TRAV >= 3 ? 1024 : 256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC)) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
                                                       const WaveInterior* __restrict__ a_wave, const WaveInterior* __restrict__ a_blas,
                                                       float* __restrict__ a_records, float* __restrict__ a_samples) {
   static_assert(NR == 3 || (NR == 2 && TRAV != 2 && !DL), "two-ray batches: sweep builds without delta / environment lights only");
-  static_assert(!(STAMP && TRAV == 3), "the streamed build has no section stamps");
+  static_assert(!(STAMP && TRAV >= 3), "the streamed builds have no section stamps");
   constexpr int C = NR - 1;                              // slot of the indirect ray
-  if constexpr (TRAV == 3) {
-    if (P_in.sc->units_done >= (unsigned long long)P_in.total_units) return;   // every unit is finished: the remaining generations are no-ops
+  constexpr bool STREAM = TRAV >= 3;                     // pt_stream.h: 3 = every ray through the ray-cast kernel, 4 = sweeps here, BVH<Triangle> walks queued
+  constexpr bool LAZY = TRAV == 1 || TRAV == 4;          // meshes with a real BVH<Triangle> are evaluated lazily inside the sweeps
+  if constexpr (STREAM) {
+    if (P_in.sc->done != 0u) return;                     // every unit is finished: the remaining generations are no-ops
   }
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
@@ -371,6 +400,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
   const uint32_t nobj = S.nobjects;
   const uint32_t Q = (S.use_bvh && TRAV != 3) ? S.wave_q : 0u;
   const uint32_t oshift = (TRAV == 3) ? P.obj_shift : 27u;   // packed hit = object slot << oshift | triangle
+  __shared__ unsigned long long s_blk[STREAM ? 36 : 1];  // streamed builds: per-wave partial sums of the block-wide exchanges
   unsigned long long stamp_acc[ST_COUNT_] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_t = 0;
   if (STAMP) stamp_t = __builtin_readcyclecounter();
@@ -439,8 +469,9 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
   // consumes the hits of the batch emitted by the previous generation (step 3 as it stands), pass 1 refills idle slots,
   // appends the next batch's rays to the queue and saves the state.
 #define ST(w) P.state[(size_t)(w) * P.nlanes + lane_global]
-  if constexpr (TRAV == 3) {
-    if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
+  uint32_t emit_mask = 0;                                // queue slots of this lane that carry a ray / walk request for the next cast
+  if constexpr (STREAM) {
+    if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
     const uint32_t fw = ST(SW_FLAGS);
     alive = (fw & 1u) != 0;
     if (alive) {
@@ -459,9 +490,11 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
       cb0 = __uint_as_float(ST(SW_CB0)); cb1 = __uint_as_float(ST(SW_CB1));
       att = spec(__uint_as_float(ST(SW_ATT)), __uint_as_float(ST(SW_ATT + 1)), __uint_as_float(ST(SW_ATT + 2)));
       pdf4 = __uint_as_float(ST(SW_PDF4)); pdf_area = __uint_as_float(ST(SW_PDF_AREA));
-      if constexpr (DL) {
+      if constexpr (DL || TRAV == 4) {                   // (TRAV 4 traces the batch again in the complete pass: every direction)
         d[0] = v3(__uint_as_float(ST(SW_D0)), __uint_as_float(ST(SW_D0 + 1)), __uint_as_float(ST(SW_D0 + 2)));
-        d[1] = v3(__uint_as_float(ST(SW_D1)), __uint_as_float(ST(SW_D1 + 1)), __uint_as_float(ST(SW_D1 + 2)));
+        if (NR > 2) d[1] = v3(__uint_as_float(ST(SW_D1)), __uint_as_float(ST(SW_D1 + 1)), __uint_as_float(ST(SW_D1 + 2)));
+      }
+      if constexpr (DL) {
         light_i = ST(SW_LIGHT_I); held_chit = ST(SW_HELD);
         pl = spec(__uint_as_float(ST(SW_PL)), __uint_as_float(ST(SW_PL + 1)), __uint_as_float(ST(SW_PL + 2)));
         dA_keep = spec(__uint_as_float(ST(SW_DA)), __uint_as_float(ST(SW_DA + 1)), __uint_as_float(ST(SW_DA + 2)));
@@ -472,18 +505,68 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
     }
   }
 
+  auto save_state = [&]() {
+    ST(SW_FLAGS) = (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
+                   (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16);
+    ST(SW_EMIT) = emit_mask | (alive ? 0x80000000u : 0u);   // (bit 31: the slot is alive - a generation without requests need not be the last)
+    if (alive) {
+      ST(SW_PX) = px; ST(SW_PY) = py; ST(SW_PIXEL_SLOT) = pixel_slot;
+      ST(SW_SAMPLES) = s_first | (s_cur << 16) | (s_count << 30);
+      ST(SW_PEND0) = pend[0];
+      if (NR > 2) ST(SW_PEND1) = pend[NR - 2];
+      ST(SW_RNG_LO) = (uint32_t)rng.state; ST(SW_RNG_HI) = (uint32_t)(rng.state >> 32);
+      ST(SW_ORG) = __float_as_uint(org.x); ST(SW_ORG + 1) = __float_as_uint(org.y); ST(SW_ORG + 2) = __float_as_uint(org.z);
+      ST(SW_DC) = __float_as_uint(d[C].x); ST(SW_DC + 1) = __float_as_uint(d[C].y); ST(SW_DC + 2) = __float_as_uint(d[C].z);
+      ST(SW_CB0) = __float_as_uint(cb0); ST(SW_CB1) = __float_as_uint(cb1);
+      ST(SW_ATT) = __float_as_uint(att.r); ST(SW_ATT + 1) = __float_as_uint(att.g); ST(SW_ATT + 2) = __float_as_uint(att.b);
+      ST(SW_PDF4) = __float_as_uint(pdf4); ST(SW_PDF_AREA) = __float_as_uint(pdf_area);
+      if constexpr (DL || TRAV == 4) {
+        ST(SW_D0) = __float_as_uint(d[0].x); ST(SW_D0 + 1) = __float_as_uint(d[0].y); ST(SW_D0 + 2) = __float_as_uint(d[0].z);
+        if (NR > 2) { ST(SW_D1) = __float_as_uint(d[1].x); ST(SW_D1 + 1) = __float_as_uint(d[1].y); ST(SW_D1 + 2) = __float_as_uint(d[1].z); }
+      }
+      if constexpr (DL) {
+        ST(SW_LIGHT_I) = light_i; ST(SW_HELD) = held_chit;
+        ST(SW_PL) = __float_as_uint(pl.r); ST(SW_PL + 1) = __float_as_uint(pl.g); ST(SW_PL + 2) = __float_as_uint(pl.b);
+        ST(SW_DA) = __float_as_uint(dA_keep.r); ST(SW_DA + 1) = __float_as_uint(dA_keep.g); ST(SW_DA + 2) = __float_as_uint(dA_keep.b);
+        ST(SW_D6) = __float_as_uint(d6_keep.r); ST(SW_D6 + 1) = __float_as_uint(d6_keep.g); ST(SW_D6 + 2) = __float_as_uint(d6_keep.b);
+        ST(SW_DCK) = __float_as_uint(dC_keep.x); ST(SW_DCK + 1) = __float_as_uint(dC_keep.y); ST(SW_DCK + 2) = __float_as_uint(dC_keep.z);
+        ST(SW_SB1) = __float_as_uint(sb1[0]); ST(SW_SB1 + 1) = __float_as_uint(sb1[1]); ST(SW_SB1 + 2) = __float_as_uint(sb1[2]);
+      }
+    }
+  };
+
   for (int pass = 0;; pass++) {
     // ---------------- 1. refill idle lanes ----------------
-    const unsigned long long need = (TRAV != 3 || pass == 1) ? __ballot(!alive) : 0ull;
-    if (need != 0ull && !(queue_empty && chunk_next == chunk_end)) {
+    const unsigned long long need = (!STREAM || pass == 1) ? __ballot(!alive) : 0ull;
+    uint32_t stream_unit = kMissTri;
+    if constexpr (STREAM) {
+      if (pass == 1) {
+        // one queue atomic per BLOCK: the waves' wants meet in LDS (a single word saturates at ~90 atomics / us, and a
+        // generation of a million slots would bring sixteen thousand of them)
+        const uint32_t want = (uint32_t)__popcll(need);
+        const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        if (lane == 0) s_blk[wave] = want;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          unsigned long long total = 0;
+          for (uint32_t w = 0; w < blockDim.x / 64u; w++) { const unsigned long long n_ = s_blk[w]; s_blk[w] = total; total += n_; }
+          s_blk[32] = total ? atomicAdd(P.queue_head, total) : (unsigned long long)P.total_units;
+        }
+        __syncthreads();
+        const unsigned long long u = s_blk[32] + s_blk[wave] + my_rank;
+        if (!alive && u < (unsigned long long)P.total_units) stream_unit = (uint32_t)u;
+        __syncthreads();                                  // (s_blk is reused below)
+      }
+    }
+    if ((!STREAM && need != 0ull && !(queue_empty && chunk_next == chunk_end)) || (STREAM && pass == 1)) {
       const uint32_t want = (uint32_t)__popcll(need);
       const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-      uint32_t given = 0, my_unit = kMissTri;
-      while (given < want) {
+      uint32_t given = 0, my_unit = stream_unit;
+      while (!STREAM && given < want) {
         if (chunk_next == chunk_end) {
           if (queue_empty) break;
           unsigned long long start = 0;
-          const uint32_t grab = (TRAV == 3) ? want - given : P.chunk;   // the streamed build cannot keep units for a later cycle
+          const uint32_t grab = P.chunk;
           if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)grab);
           start = __shfl(start, 0);
           if (start >= P.total_units) { queue_empty = true; break; }
@@ -537,9 +620,10 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
         }
       }
     }
-    if constexpr (TRAV == 3) {
-      if (pass == 1) {
-        // ---- the next batch's rays to the queue (slot-major per wave, one atomic per wave), the slot's state to HBM ----
+    if constexpr (STREAM) {
+      if (pass == 1 && TRAV == 3) {
+        // ---- the next batch's rays to their fixed queue positions [batch slot][path slot]; pt_compact_kernel makes the
+        // dense list the ray-cast kernel pulls from (no atomics here) ----
         bool eact[NR];
         float eb1[NR];
 #pragma unroll
@@ -551,51 +635,16 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
           for (int r = 0; r < NR; r++) eb1[r] = sb1[r];
         } else if (burst) { if (NR > 1) eact[1] = alive && actA; if (NR > 2) eact[NR - 1] = alive && actB; }
         else if (NR == 3) { eact[0] = alive && actA; eact[1] = alive && actB; }
-        uint32_t epos[NR], etotal = 0;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-          const unsigned long long m = __ballot(eact[r]);
-          epos[r] = etotal + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          etotal += (uint32_t)__popcll(m);
-        }
-        if (etotal != 0u) {
-          uint32_t ebase = 0;
-          if (lane == 0) ebase = atomicAdd(&P.sc->nrays[P.gen & 1u], etotal);
-          ebase = (uint32_t)__shfl((int)ebase, 0);
-#pragma unroll
-          for (int r = 0; r < NR; r++) {
-            if (eact[r]) {
-              const uint32_t i = ebase + epos[r];
-              P.ray_o[i] = make_float4(org.x, org.y, org.z, cb0);
-              P.ray_d[i] = make_float4(d[r].x, d[r].y, d[r].z, eb1[r]);
-              P.ray_id[i] = (lane_global << 2) | (uint32_t)r;
-            }
+          if (eact[r]) {
+            const size_t i = (size_t)r * P.nlanes + lane_global;
+            P.ray_o[i] = make_float4(org.x, org.y, org.z, cb0);
+            P.ray_d[i] = make_float4(d[r].x, d[r].y, d[r].z, eb1[r]);
+            emit_mask |= 1u << r;
           }
         }
-        ST(SW_FLAGS) = (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
-                       (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16);
-        if (alive) {
-          ST(SW_PX) = px; ST(SW_PY) = py; ST(SW_PIXEL_SLOT) = pixel_slot;
-          ST(SW_SAMPLES) = s_first | (s_cur << 16) | (s_count << 30);
-          ST(SW_PEND0) = pend[0];
-          if (NR > 2) ST(SW_PEND1) = pend[NR - 2];
-          ST(SW_RNG_LO) = (uint32_t)rng.state; ST(SW_RNG_HI) = (uint32_t)(rng.state >> 32);
-          ST(SW_ORG) = __float_as_uint(org.x); ST(SW_ORG + 1) = __float_as_uint(org.y); ST(SW_ORG + 2) = __float_as_uint(org.z);
-          ST(SW_DC) = __float_as_uint(d[C].x); ST(SW_DC + 1) = __float_as_uint(d[C].y); ST(SW_DC + 2) = __float_as_uint(d[C].z);
-          ST(SW_CB0) = __float_as_uint(cb0); ST(SW_CB1) = __float_as_uint(cb1);
-          ST(SW_ATT) = __float_as_uint(att.r); ST(SW_ATT + 1) = __float_as_uint(att.g); ST(SW_ATT + 2) = __float_as_uint(att.b);
-          ST(SW_PDF4) = __float_as_uint(pdf4); ST(SW_PDF_AREA) = __float_as_uint(pdf_area);
-          if constexpr (DL) {
-            ST(SW_D0) = __float_as_uint(d[0].x); ST(SW_D0 + 1) = __float_as_uint(d[0].y); ST(SW_D0 + 2) = __float_as_uint(d[0].z);
-            ST(SW_D1) = __float_as_uint(d[1].x); ST(SW_D1 + 1) = __float_as_uint(d[1].y); ST(SW_D1 + 2) = __float_as_uint(d[1].z);
-            ST(SW_LIGHT_I) = light_i; ST(SW_HELD) = held_chit;
-            ST(SW_PL) = __float_as_uint(pl.r); ST(SW_PL + 1) = __float_as_uint(pl.g); ST(SW_PL + 2) = __float_as_uint(pl.b);
-            ST(SW_DA) = __float_as_uint(dA_keep.r); ST(SW_DA + 1) = __float_as_uint(dA_keep.g); ST(SW_DA + 2) = __float_as_uint(dA_keep.b);
-            ST(SW_D6) = __float_as_uint(d6_keep.r); ST(SW_D6 + 1) = __float_as_uint(d6_keep.g); ST(SW_D6 + 2) = __float_as_uint(d6_keep.b);
-            ST(SW_DCK) = __float_as_uint(dC_keep.x); ST(SW_DCK + 1) = __float_as_uint(dC_keep.y); ST(SW_DCK + 2) = __float_as_uint(dC_keep.z);
-            ST(SW_SB1) = __float_as_uint(sb1[0]); ST(SW_SB1 + 1) = __float_as_uint(sb1[1]); ST(SW_SB1 + 2) = __float_as_uint(sb1[2]);
-          }
-        }
+        save_state();
         break;
       }
     } else {
@@ -607,7 +656,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
     SECTION_END(ST_REFILL)
 
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
-    if (TRAV != 2) {
+    if (TRAV != 2 && !(TRAV == 4 && pass == 1)) {
       if (DL && sh_phase) cnt.v[C_RAYS] += alive ? (1u + (sa1 ? 1u : 0u) + (sa2 ? 1u : 0u)) : 0u;
       else if (NR == 3) cnt.v[C_RAYS] += alive ? (1u + (actA ? 1u : 0u) + (actB ? 1u : 0u)) : 0u;
       else {
@@ -659,7 +708,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
       for (int r = 0; r < NR; r++) res[r] = no_hit();
       for (uint32_t k = 0; k < nobj; k++) {
         bool h[NR]; float dd[NR]; uint32_t tt[NR];
-        object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, act, cidx);
+        object_testN<LAZY, NR, TRAV == 4>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, act, cidx, &P, lane_global, pass == 1, &emit_mask);
 #pragma unroll
         for (int r = 0; r < NR; r++) fold(res[r], h[r], dd[r], k, tt[r]);
       }
@@ -709,7 +758,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
         // not known yet (bottom-up), so that part is assumed.  Rays that do not need it get "no hit", which the
         // combination below never selects.
         auto lazy_leaf = [&](int32_t ref, uint32_t n) {
-          if (TRAV != 1 || ref >= 0 || n != 1u) return false;
+          if (!LAZY || ref >= 0 || n != 1u) return false;
           const Object& ob = S.objects[(uint32_t)~ref];
           return ob.kind == OBJ_MESH && ob.use_bvh != 0u && ob.nrec > 0u;
         };
@@ -723,7 +772,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
             const uint32_t first = (uint32_t)~ref;
             for (uint32_t k = first; k < first + n; k++) {
               bool h[NR]; float dd[NR]; uint32_t tt[NR];
-              object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, need, cidx);
+              object_testN<LAZY, NR, TRAV == 4>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, need, cidx, &P, lane_global, pass == 1, &emit_mask);
 #pragma unroll
               for (int r = 0; r < NR; r++) fold(out[r], h[r], dd[r], k, tt[r]);
             }
@@ -739,11 +788,15 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
             need[r] = act[r] && (f & 3u) != 0 && (nearer || second);
           }
         };
-        if constexpr (TRAV != 1) {                       // no per-lane walks: both children straight, in order
+        if constexpr (!LAZY) {                           // no per-lane walks: both children straight, in order
           eval_child(W.l_ref, W.l_cnt, L, act);
           eval_child(W.r_ref, W.r_cnt, R, act);
         } else {
         const bool lazy_l = lazy_leaf(W.l_ref, W.l_cnt), lazy_r = lazy_leaf(W.r_ref, W.r_cnt);
+        // TRAV 4: the walks are queued in the probe pass, when no mesh result exists yet, and read back in the complete pass:
+        // the set of rays that "need" a mesh must not depend on any mesh's result, so a sibling whose subtree holds such a
+        // mesh counts as unknown (a superset again; what is not needed is never selected)
+        const uint32_t lz = (TRAV == 4) ? S.wave_lazy[q] : 0u;
         const bool right_first = lazy_l && !lazy_r;      // the sibling of a lazy leaf goes first
         Hit first_out[NR];
 #pragma unroll
@@ -755,7 +808,7 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
           const int32_t ref = left ? W.l_ref : W.r_ref;
           const uint32_t n = left ? W.l_cnt : W.r_cnt;
           bool need[NR];
-          if (left ? lazy_l : lazy_r) need_of(left, first_out, t == 1, need);
+          if (left ? lazy_l : lazy_r) need_of(left, first_out, t == 1 && !(TRAV == 4 && (lz & (left ? 2u : 1u)) != 0u), need);
           else {
 #pragma unroll
             for (int r = 0; r < NR; r++) need[r] = act[r];
@@ -791,6 +844,12 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
       }
     }
 
+    if constexpr (TRAV == 4) {
+      if (pass == 1) {                                   // the probe pass: the walk requests are out, the batch waits in HBM
+        save_state();
+        break;
+      }
+    }
     // ---------------- 3. finish the previous bounce / unpack the burst, then terminate or shade ----------------
     if (batch_ready) {
       uint32_t chit = kRetMiss;                         // packed closest hit that decides how the current path goes on
@@ -1029,12 +1088,21 @@ __global__ __launch_bounds__(256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : SRT_WA
 #undef SLOT
 #undef ST
   unsigned long long r = cnt.v[C_RAYS], rt = (NR == 3) ? cnt.v[C_RAYS] : traced;
-  unsigned long long uf = units_finished;
-  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); if (TRAV == 3) uf += __shfl_down(uf, off); }
-  if (lane == 0) {
-    if (TRAV != 3 || r != 0ull) atomicAdd(P.ray_counter, r);
-    if (NR == 2 && (TRAV != 3 || r != rt)) atomicAdd(P.elided_counter, r - rt);
-    if (TRAV == 3 && uf != 0ull) atomicAdd(&P.sc->units_done, uf);
+  for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); }
+  if constexpr (STREAM) {
+    // per-block sums into the block's own words (no atomics; pt_stream_finish_kernel adds them up after the last generation)
+    (void)units_finished;
+    if (lane == 0) { s_blk[wave] = r; s_blk[16 + wave] = r - rt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long a = 0, b = 0;
+      for (uint32_t w = 0; w < blockDim.x / 64u; w++) { a += s_blk[w]; b += s_blk[16 + w]; }
+      if (a) P.block_counters[2 * (size_t)blockIdx.x] += a;
+      if (b) P.block_counters[2 * (size_t)blockIdx.x + 1] += b;
+    }
+  } else if (lane == 0) {
+    atomicAdd(P.ray_counter, r);
+    if (NR == 2) atomicAdd(P.elided_counter, r - rt);
   }
 }
 

@@ -50,7 +50,7 @@ int emu_commit(void* h, int use_bvh) {
   DScene& S = e->S;
   S.nodes = F.nodes.data(); S.tris = F.tris.data(); S.tri_nrm = F.tri_nrm.data(); S.objects = F.objects.data();
   S.lights = F.lights.data(); S.light_tris = F.light_tris.data(); S.materials = F.materials.data();
-  S.wave_tlas = F.wave_tlas.data(); S.blas_recs = F.blas_recs.data();
+  S.wave_tlas = F.wave_tlas.data(); S.blas_recs = F.blas_recs.data(); S.wave_lazy = F.wave_lazy.data();
   S.wave_q = (uint32_t)F.wave_tlas.size();
   S.nobjects = (uint32_t)F.objects.size(); S.nlights = (uint32_t)F.lights.size(); S.tlas_nodes = F.tlas_nodes;
   S.use_bvh = F.use_bvh ? 1u : 0u; S.light_tri_first = F.light_tri_first;

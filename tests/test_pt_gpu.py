@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 GOLDENS = sorted(glob.glob(os.path.join(H.GOLDEN, "pt_*.npz")))
 TOL = 1e-4  # north_star tolerance, per channel, L-inf (reported next to the bit-exact verdict)
 # kernel modes (include/srt_pt.h) that take scenes with a real BVH<Triangle>; the second list also honours srt_pt_set_elision
-MESH_KERNEL_MODES = (0, 1, 2, 4, 5, 6)
-MESH_ELISION_MODES = (2, 4, 6)
+MESH_KERNEL_MODES = (0, 1, 2, 4, 5, 6, 7)
+MESH_ELISION_MODES = (2, 4, 6, 7)
 
 
 def bits_equal(a, b):
@@ -583,7 +583,7 @@ def test_random_scenes_all_kernels(srt):
             continue
         pt = make_pt(srt, scene, w, h, depth, use_bvh)
         rays = set()
-        for mode, elide in ((2, False), (2, True), (4, True), (1, False), (5, False), (6, False), (6, True)):
+        for mode, elide in ((2, False), (2, True), (4, True), (1, False), (5, False), (6, False), (6, True), (7, False), (7, True)):
             pt.set_kernel(mode)
             pt.set_elision(elide)
             pt.ray_count(reset=True)

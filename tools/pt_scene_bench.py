@@ -23,7 +23,7 @@ pt.set_params(size, size, spp, 8, True)
 t = time.perf_counter(); pt.build_scene(scene); print(f"build_scene {time.perf_counter()-t:.2f} s ({scene['name']})")
 pt.set_camera(scene["camera"])
 imgs = []
-modes = tuple(int(m) for m in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1, 2, 4, 5)
+modes = tuple(int(m) for m in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1, 2, 4, 5, 6)
 for mode in modes:
     pt.set_kernel(mode)
     pt.render_epoch(0, 0, 1)
