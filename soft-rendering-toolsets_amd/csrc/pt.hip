@@ -594,8 +594,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   // the logic kernel: 1024-thread blocks; the streamed sweeps keep their per-wave slots in LDS (16 waves)
   const size_t nq = (trav == 4 && F.use_bvh) ? F.wave_tlas.size() : 0;
   const size_t lds_per_wave = (size_t)(nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);
-  uint32_t lthreads = kStreamBlock;                       // fewer waves per block when a larger top-level tree needs more slots
-  while (lthreads > 256u && (lthreads / 64u) * lds_per_wave > 150u * 1024u) lthreads /= 2u;
+  const uint32_t lthreads = kStreamBlock;
   const size_t logic_lds = (size_t)(lthreads / 64u) * lds_per_wave;
   const void* lkern = trav == 4 ? (two ? (const void*)pt_wave_kernel<false, 4, false, 2> : dl ? (const void*)pt_wave_kernel<false, 4, true, 3> : (const void*)pt_wave_kernel<false, 4, false, 3>)
                                 : (two ? (const void*)pt_wave_kernel<false, 3, false, 2> : dl ? (const void*)pt_wave_kernel<false, 3, true, 3> : (const void*)pt_wave_kernel<false, 3, false, 3>);
@@ -617,7 +616,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     P.units3 = px * P.groups3;
     P.total_units = px * (P.groups3 + P.singles);
     // path slots: every unit its own while they are few, else a fixed population that is refilled from the unit queue
-    uint32_t want_slots = pt->stream_slots ? pt->stream_slots : (getenv("SRT_STREAM_SLOTS") ? (uint32_t)atoi(getenv("SRT_STREAM_SLOTS")) : (1u << 20));
+    uint32_t want_slots = pt->stream_slots ? pt->stream_slots : (getenv("SRT_STREAM_SLOTS") ? (uint32_t)atoi(getenv("SRT_STREAM_SLOTS")) : (1u << 21));
     if (want_slots < lthreads) want_slots = lthreads;
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(((uint64_t)P.total_units + lthreads - 1) / lthreads * lthreads,
                                                          (want_slots + lthreads - 1) / lthreads * lthreads);
@@ -650,9 +649,14 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       C.depth = depth; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
       C.walk_nr = trav == 4 ? burst : 0u;
       for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];
-      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 16u;
+      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 8u;
       C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
       if (C.fetch_min < 1u) C.fetch_min = 1u;
+      C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 8u;
+      C.object_min = getenv("SRT_CAST_OBJECT") ? (uint32_t)atoi(getenv("SRT_CAST_OBJECT")) : 16u;
+      C.pops = getenv("SRT_CAST_POPS") ? (uint32_t)atoi(getenv("SRT_CAST_POPS")) : 2u;
+      if (C.leaf_min < 1u) C.leaf_min = 1u;
+      if (C.object_min < 1u) C.object_min = 1u;
       C.stats = pt->d_cast_stats;
       const dim3 lgrid(nblocks), lblock(lthreads);
       const dim3 cgrid((nlanes + kCompactChunk - 1) / kCompactChunk);
@@ -748,7 +752,7 @@ int srt_pt_destroy(srt_pt* pt) {
     if (pt->d_cast_stats) {                               // SRT_CAST_STATS=1 (diagnostic): the sums, on stderr
       unsigned long long h[CS_COUNT];
       static const char* names[CS_COUNT] = {"outer", "fetch", "interior_trips", "interior_lanes", "leaf_trips", "leaf_lanes", "leaf_tris",
-                                            "object_trips", "object_lanes", "pop_trips", "pop_lanes", "walking_lanes"};
+                                            "object_trips", "object_lanes", "cycles_fetch", "cycles_interior", "walking_lanes", "cycles_leaf", "cycles_object"};
       if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, pt->d_cast_stats, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
         for (int i = 0; i < CS_COUNT; i++) fprintf(stderr, "[srt] cast %s %llu\n", names[i], h[i]);
       (void)hipFree(pt->d_cast_stats);

@@ -86,7 +86,10 @@ struct CastParams {
   uint32_t* head;            // queue head of this generation
   uint32_t depth;            // frames per lane
   uint32_t fetch_min;        // idle lanes of a wave that trigger a fetch
-  uint32_t interior_min;     // lanes at interior records that keep the wave in the interior-step loop
+  uint32_t interior_min;     // (unused by the phase scheduler; kept for experiments)
+  uint32_t leaf_min;         // lanes waiting at BVH<Triangle> leaves that make the wave run the leaf phase
+  uint32_t object_min;       // lanes waiting at objects that make the wave run the object phase
+  uint32_t pops;             // pops a lane may take per walk trip (1 or 2)
   uint32_t obj_shift;
   unsigned long long* stats;   // STATS build only: CS_* sums over all waves
 };
@@ -149,35 +152,35 @@ __global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_c
 
 // STATS build (diagnostic, SRT_CAST_STATS=1): how the waves spend their loop trips.
 enum { CS_OUTER = 0, CS_FETCH, CS_INTERIOR_TRIPS, CS_INTERIOR_LANES, CS_LEAF_TRIPS, CS_LEAF_LANES, CS_LEAF_TRIS, CS_OBJECT_TRIPS, CS_OBJECT_LANES,
-       CS_POP_TRIPS, CS_POP_LANES, CS_WALKING_LANES, CS_COUNT };
+       CS_T_FETCH, CS_T_INTERIOR, CS_WALKING_LANES, CS_T_LEAF, CS_T_OBJECT, CS_COUNT };
 
-// Brings a lane that has just taken a step to a state one of the three phases below picks up: frames are unwound on
-// the spot (a few LDS words each), a BVH<Object> leaf becomes "its objects next", the end of a mesh's tree becomes
-// "finish Object::hit" (object phase), the end of the top-level tree finishes the ray.
+// One pop: the top frame of a lane in FM_UNWIND - the visit rule for the farther child, or Trace::min of the two children
+// (flat_pop) - or, with no frame of the current tree left, the end of that tree: a mesh's tree hands over to the object
+// phase (Object::hit is finished there), the top-level tree finishes the ray.
 template <typename StackT>
-SRT_DEV void cast_settle(FlatState& F, const StackT& stack) {
-  for (;;) {
-    if (F.mode == FM_UNWIND) {
-      if (flat_plain_frame(F)) { flat_pop(F, stack); continue; }
-      if (F.level) { F.mode = FM_OBJECT; return; }
-      F.res0 = F.ret; F.mode = FM_DONE;
-      return;
-    }
-    if (F.mode == FM_NODE && F.cur < 0 && F.level == 0u) {
-      const uint32_t packed = (uint32_t)~F.cur;
-      F.obj_i = packed >> 3; F.obj_end = F.obj_i + (packed & 7u);
-      F.acc = flat_no_hit();
-      F.mode = FM_OBJECT;
-    }
-    return;
+SRT_DEV void cast_unwind_step(FlatState& F, const StackT& stack) {
+  if (flat_plain_frame(F)) flat_pop(F, stack);
+  else if (F.level) F.mode = FM_OBJECT;
+  else { F.res0 = F.ret; F.mode = FM_DONE; }
+}
+// A lane that has just arrived at a BVH<Object> leaf: its objects are next.
+SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
+  if (F.mode == FM_NODE && F.cur < 0 && F.level == 0u) {
+    const uint32_t packed = (uint32_t)~F.cur;
+    F.obj_i = packed >> 3; F.obj_end = F.obj_i + (packed & 7u);
+    F.acc = flat_no_hit();
+    F.mode = FM_OBJECT;
   }
 }
 
 // scene.hit for a queue of rays (see the head comment).  Every trip of the loop the wave runs ONE of three phases for the
-// lanes that stand there - interior records (cheap, by far the most frequent), Object::hit (ray -> object space, sphere /
-// one-leaf mesh on the spot, or into / out of a mesh's tree), a BVH<Triangle> leaf's triangles - and the others wait:
-// interior steps as long as enough lanes take part, else the fuller of the two expensive phases, so that those run with
-// the lanes that have piled up in front of them instead of with whoever happens to be there.
+// lanes that stand there, and the others wait:
+//   walk    one step per lane, no inner loops: an interior record (both child boxes, nearer / farther, push) or one pop
+//           of the lane's LDS stack - cheap and by far the most frequent;
+//   leaf    the <= 4 triangles of a BVH<Triangle> leaf, loaded together, their twelve IEEE quotients refined together;
+//   object  Object::hit: ray -> object space, sphere / one-leaf mesh on the spot, or into / out of a mesh's tree.
+// The two expensive phases run when enough lanes have piled up in front of them (or nothing else can run), so they execute
+// with those lanes instead of with whoever happens to be there.
 template <bool STATS>
 __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
@@ -200,14 +203,16 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
     for (int i = 0; i < CS_COUNT; i++) cs[i] = 0;
 #define CAST_STAT(i, v) if (STATS) cs[i] += (v)
   for (;;) {
-    const bool at_int = F.mode == FM_NODE && F.cur >= 0;
-    const bool at_leaf = F.mode == FM_NODE && F.cur < 0;   // (a BVH<Triangle> leaf: cast_settle has turned the others into objects)
+    const bool at_walk = (F.mode == FM_NODE && F.cur >= 0) || F.mode == FM_UNWIND;
+    const bool at_leaf = F.mode == FM_NODE && F.cur < 0;   // (a BVH<Triangle> leaf: the others have become objects)
     const bool at_obj = F.mode == FM_OBJECT;
     const unsigned long long idle = __ballot(F.mode == FM_DONE);
     const uint32_t nidle = (uint32_t)__popcll(idle);
-    const uint32_t n_int = (uint32_t)__popcll(__ballot(at_int)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf)),
+    const uint32_t n_walk = (uint32_t)__popcll(__ballot(at_walk)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf)),
                    n_obj = (uint32_t)__popcll(__ballot(at_obj));
     CAST_STAT(CS_OUTER, 1); CAST_STAT(CS_WALKING_LANES, 64u - nidle);
+    unsigned long long t0 = 0;
+    if (STATS) t0 = __builtin_readcyclecounter();
     if (nidle == 64u || (!exhausted && nidle >= P.fetch_min)) {
       CAST_STAT(CS_FETCH, 1);
       if (have && F.mode == FM_DONE) {                    // results out: every idle lane at once
@@ -248,28 +253,34 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
             F.mode = FM_NODE;
           } else {
             flat_begin(F, S, wo, wd, wd, wd, wb0, wb1, true, false, false);
+            cast_enter_leaf_objects(F);
           }
           have = true;
         }
         if (start + nidle >= nrays) exhausted = true;
       }
+      CAST_STAT(CS_T_FETCH, __builtin_readcyclecounter() - t0);
       if (__ballot(F.mode != FM_DONE) == 0ull && exhausted) break;
       continue;
     }
-    if (n_int >= P.interior_min || (n_int != 0u && n_int >= n_obj && n_int >= n_leaf)) {
-      CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_int);
-      if (at_int) {
-        flat_interior(F, stack, S);
-        cast_settle(F, stack);
-      }
-    } else if (n_obj != 0u && n_obj >= n_leaf) {
+    const bool run_leaf = n_leaf >= P.leaf_min || (n_walk == 0u && n_leaf > n_obj);
+    const bool run_obj = !run_leaf && (n_obj >= P.object_min || n_walk == 0u);
+    if (!run_leaf && !run_obj) {
+      CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_walk);
+      if (F.mode == FM_UNWIND) {
+        cast_unwind_step(F, stack);
+        if (P.pops > 1u && F.mode == FM_UNWIND) cast_unwind_step(F, stack);   // (a second pop costs less than another trip)
+      } else if (at_walk) flat_interior(F, stack, S);
+      cast_enter_leaf_objects(F);
+      CAST_STAT(CS_T_INTERIOR, __builtin_readcyclecounter() - t0);
+    } else if (run_obj) {
       CAST_STAT(CS_OBJECT_TRIPS, 1); CAST_STAT(CS_OBJECT_LANES, n_obj);
       if (at_obj) {
         if (F.level) flat_exit(F, S, wo, wd, wd, wd, wb0, wb1);   // back from a mesh's tree: finish its Object::hit
         else if (F.obj_i < F.obj_end) flat_object(F, S);          // the next object of the leaf / list
         if (F.mode == FM_OBJECT && F.obj_i >= F.obj_end) { F.ret = F.acc; F.mode = FM_UNWIND; }
-        cast_settle(F, stack);
       }
+      CAST_STAT(CS_T_OBJECT, __builtin_readcyclecounter() - t0);
     } else {
       if (STATS) {
         unsigned long long t = at_leaf ? (((uint32_t)~F.cur) & 7u) : 0u;
@@ -277,9 +288,29 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
         cs[CS_LEAF_TRIPS]++; cs[CS_LEAF_LANES] += n_leaf; cs[CS_LEAF_TRIS] += __shfl(t, 0);
       }
       if (at_leaf) {
-        flat_leaf(F, S);
-        cast_settle(F, stack);
+        // BVH<Triangle> leaf: fold its triangles in order (spare slots repeat the last one: sane operands, never folded)
+        const uint32_t packed = (uint32_t)~F.cur;
+        const uint32_t first = F.tri_base + (packed >> 3), n = packed & 7u;
+        Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
+        F.ret = flat_no_hit();
+        if (n != 0u && n <= 4u) {
+          Tri g[4];
+#pragma unroll
+          for (uint32_t i = 0; i < 4u; i++) g[i] = S.tris[first + (i < n ? i : n - 1u)];
+          TriHit th[4];
+          tri_hit_leaf4(g, ray, th);
+#pragma unroll
+          for (uint32_t i = 0; i < 4u; i++)
+            if (i < n) fold(F.ret, th[i].hit, th[i].dist, 0, first + i);
+        } else {
+          for (uint32_t i = 0; i < n; i++) {
+            const TriHit th = tri_hit(S.tris[first + i], ray);
+            fold(F.ret, th.hit, th.dist, 0, first + i);
+          }
+        }
+        F.mode = FM_UNWIND;
       }
+      CAST_STAT(CS_T_LEAF, __builtin_readcyclecounter() - t0);
     }
   }
 #undef CAST_STAT

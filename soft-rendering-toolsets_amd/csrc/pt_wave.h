@@ -81,7 +81,8 @@ struct WaveParams {
   uint32_t obj_shift;        // packed hit = object slot << obj_shift | triangle
 };
 
-constexpr uint32_t kStreamBlock = 1024;   // threads per block of the streamed logic kernels (one atomic per block and counter)
+constexpr uint32_t kStreamBlock = 256;    // threads per block of the streamed logic kernels (one queue atomic per block; four waves, so
+                                          // that a CU takes the next block as soon as four waves are done)
 constexpr uint32_t kMaxLazy = 4;          // TRAV 4: meshes with a real BVH<Triangle> whose walks are queued
 
 // Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
@@ -373,7 +374,10 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC3T
 #define SRT_WAVE_OCC3T 4
 #endif
-__global__ __launch_bounds__(TRAV >= 3 ? 1024 : 256, NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC)) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+#ifndef SRT_STREAM_OCC
+#define SRT_STREAM_OCC 3
+#endif
+__global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC))) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
