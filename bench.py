@@ -31,6 +31,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth (8 XCDs x 4 MiB), same guide: what bounds a working set that lives in L2 / Infinity Cache
+SIMDS = 256 * 4
+VALU_PEAK_GUIDE = SIMDS * 2.4e9 / 2.0     # wave-instructions / s: one wave64 VALU op per 2 cycles per SIMD at 2.4 GHz (the guide)
+VALU_NS_UBENCH = 1.09                     # measured issue interval of a SIMD with >= 2 waves (tools/ubench/pk_rate.hip)
+
+
+def kernel_source_sha():
+    """Digest of the kernel sources a profile was taken on: stale PMC numbers must not end up in a fresh bench line."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "soft-rendering-toolsets_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")) or f == "Makefile":
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def bytes_per_ray(counters):
@@ -165,32 +180,152 @@ def raster_bench(device, frames=30, warmup=3):
     }
 
 
-def traffic_bytes(size, spp, world):
-    """HBM bytes per pt_wave_kernel launch from the committed PMC passes (profiles/*_traffic.json, produced by
-    tools/collect_profiles.sh on this workload); None when the run is not the profiled workload."""
+def profile_doc(scene, size, spp, world):
+    """(doc, why_not): the committed PMC reduction (profiles/*_traffic.json, tools/collect_profiles.sh) of THIS workload taken on
+    THESE kernel sources - matched on scene / size / spp / GPUs and on the digest of csrc/ - or (None, reason)."""
     import glob
+    sha = kernel_source_sha()
+    seen = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             doc = json.load(open(path))
         except (OSError, ValueError):
             continue
         wl = doc.get("workload", {})
-        if (wl.get("size"), wl.get("spp_per_step"), wl.get("n_gpus")) == (size, spp, world):
-            return doc.get("hbm_bytes_per_launch"), doc
-    return None, None
+        if (wl.get("scene"), wl.get("size"), wl.get("spp_per_step"), wl.get("n_gpus")) != (scene, size, spp, world):
+            continue
+        if doc.get("kernel_source_sha16") == sha:
+            doc["_file"] = os.path.relpath(path, ROOT)
+            return doc, None
+        seen = os.path.relpath(path, ROOT)
+    if seen:
+        return None, f"{seen} was taken on other kernel sources (csrc digest now {sha}): counters not reported"
+    return None, "no committed PMC pass for this workload"
 
 
-def valu_utilisation(doc, kernel_ms):
-    """The wave kernel is bound by vector-instruction issue, not by HBM or MFMA: wave-instructions per launch (SQ_INSTS_VALU
-    of the committed PMC pass) x the measured issue interval of a SIMD (tools/ubench/pk_rate.hip) / the live launch time."""
+def valu_roofline(doc, kernel_ms):
+    """Vector-instruction issue, the resource that binds the wave kernel: wave-instructions per launch (SQ_INSTS_VALU of the
+    committed PMC pass) / the live launch time, against (i) the guide's rate - one wave64 VALU op per 2 cycles per SIMD at
+    2.4 GHz - and (ii) the issue interval a SIMD was measured to sustain (tools/ubench/pk_rate.hip, 1.09 ns)."""
     sq = (doc or {}).get("sq_per_launch") or {}
     if "SQ_INSTS_VALU" not in sq or not kernel_ms:
         return None
-    simds = 256 * 4
-    busy_ms = sq["SQ_INSTS_VALU"] / simds * doc["valu_issue_ns"] * 1e-6
-    return {"bound": "valu issue", "wave_instructions_per_launch": sq["SQ_INSTS_VALU"], "issue_ns_per_simd": doc["valu_issue_ns"],
-            "simds": simds, "frac": busy_ms / kernel_ms,
-            "source": "profiles/*_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU ...), tools/ubench/pk_rate.hip"}
+    rate = sq["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
+    return {"wave_instructions_per_launch": sq["SQ_INSTS_VALU"], "achieved_per_s": rate, "peak_guide_per_s": VALU_PEAK_GUIDE,
+            "frac_guide": rate / VALU_PEAK_GUIDE, "issue_ns_per_simd_ubench": VALU_NS_UBENCH,
+            "frac_ubench": rate / (SIMDS / (VALU_NS_UBENCH * 1e-9)),
+            "source": f"{doc['_file']} (rocprofv3 --pmc SQ_INSTS_VALU ...), MI355X_MICROARCH.md, tools/ubench/pk_rate.hip"}
+
+
+def pt_roofline(cnt, rays_per_launch, kernel_ms, doc, why_not, kernel, scratch_bytes_per_launch=None, extra=None):
+    """The `roofline` object of a path-tracer workload.  SURVEY.md section 8(d)'s figure: algorithmic bytes per ray (32 B per node visited +
+    128 B per object entered + 36 B per triangle tested + 4 B per sphere + 36 B hit normals, the counts being the reference
+    traversal's own averages from an instrumented launch) x rays per launch / the kernel's launch time, against the HBM peak.
+    For a cache-resident scene that figure is not a bound (it exceeds the peak); what binds the kernel - vector-instruction
+    issue - is reported from the PMC pass of the same sources when one is committed, and is then the headline fraction."""
+    bpr = bytes_per_ray(cnt)
+    alg_bytes = bpr * rays_per_launch + (scratch_bytes_per_launch or 0.0)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_ray": bpr, "ray_state_bytes_per_launch": scratch_bytes_per_launch,
+           "frac_of_l2_peak": achieved / L2_PEAK_GBS, "l2_peak": L2_PEAK_GBS,
+           "note": "SURVEY.md 8(d): algorithmic bytes (scene reads by the reference's traversal counts + ray state spilled to memory) / "
+                   "kernel time; the scene is served by the scalar cache / L2 / Infinity Cache, so against the HBM peak this may exceed 1 by construction"}
+    valu = valu_roofline(doc, kernel_ms)
+    traffic = (doc or {}).get("hbm_bytes_per_launch")
+    out = dict(hbm)
+    if valu:
+        out = {"bound": "valu", "achieved": valu["achieved_per_s"] / 1e9, "peak": VALU_PEAK_GUIDE / 1e9, "unit": "G wave-instructions/s",
+               "frac": valu["frac_guide"], "frac_ubench_ceiling": valu["frac_ubench"], "valu": valu, "hbm": hbm}
+    out.update({"traffic": traffic, "kernel": kernel, "kernel_ms": kernel_ms,
+                "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"}})
+    if traffic is not None:
+        out["traffic_frac_of_hbm_peak"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["traffic_over_algorithmic_scratch"] = (traffic / scratch_bytes_per_launch) if scratch_bytes_per_launch else None
+        out["l2_hit_rate"] = (doc["TCC_HIT_sum"] / (doc["TCC_HIT_sum"] + doc["TCC_MISS_sum"])) if doc.get("TCC_HIT_sum") else None
+    if why_not:
+        out["counters"] = why_not
+    if extra:
+        out.update(extra)
+    return out
+
+
+def cfg5_bench(device, args, steps=2):
+    """BASELINE configs[4]'s workload on one GPU as a second object of the line: the Cornell box with a 131 072-triangle glass
+    mesh (80 127-node BVH<Triangle>, depth 18) and the mirror sphere, 1024 x 1024, 64 spp per step.  The streamed sweeps
+    (kernel mode 7): wave-uniform sweeps in the logic kernel, the mesh's walks queued to the persistent ray-cast kernel."""
+    import hashlib
+
+    import torch
+
+    import srt_amd
+    from soft_rendering_toolsets_amd import scenes
+
+    W = H = args.size
+    spp = args.spp_per_step
+    scene = scenes.cornell_with_mesh(7, "glass")
+    pt = srt_amd.Pathtracer(device)
+    pt.set_params(W, H, spp * steps, args.depth, True)
+    t0 = time.perf_counter()
+    pt.build_scene(scene)
+    build_s = time.perf_counter() - t0
+    pt.set_camera(scene["camera"])
+    pt.set_tiling(32, 32, 0, 1)
+    form = pt.kernel_form()
+    _, per_rank, fpt = pt.tile_info()
+    dev = torch.device("cuda", device)
+    S = torch.cuda.current_stream()
+    tiles = torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev)
+    image = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+    acc = torch.zeros(W * H * 3, dtype=torch.float32, device=dev)
+    pt.render_epoch_device(S.cuda_stream, args.seed, 0, spp, tiles.data_ptr())     # warm-up
+    torch.cuda.synchronize()
+    pt.ray_count(reset=True)
+    pt.kernel_time(enable=True)
+    if form >= 3:
+        pt.stream_times(enable=True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pt.render_epoch_device(S.cuda_stream, args.seed, i * spp, spp, tiles.data_ptr())
+        pt.untile_device(S.cuda_stream, tiles.data_ptr(), image.data_ptr())
+        pt.accumulate_device(S.cuda_stream, acc.data_ptr(), image.data_ptr(), image.numel(), i + 1)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rays, cams = pt.ray_count(reset=True)
+    ms_total, launches = pt.kernel_time(enable=False)
+    kernel_ms = ms_total / max(1, launches)
+    split = None
+    if form >= 3:
+        ms3, gens = pt.stream_times(enable=False)
+        split = {k: v / steps for k, v in ms3.items()}
+        split["generations_enqueued_per_step"] = gens // steps
+    rng = np.random.default_rng(1)
+    n = 1 << 15
+    xs, ys = rng.integers(0, W, n).astype(np.uint32), rng.integers(0, H, n).astype(np.uint32)
+    pt.trace_samples(args.seed, xs, ys, rng.integers(0, spp * steps, n).astype(np.uint32))
+    cnt = pt.counters()
+    doc, why_not = profile_doc("cfg5", W, spp, 1)
+    bounces = max(0.0, (rays - cams) / steps / 3.0)
+    scratch = 64.0 * bounces + 32.0 * cams / steps
+    if form >= 3:
+        scratch += (rays / steps / 2.8) * 2 * 30 * 4 + 0.32 * rays / steps * (2 * 36 + 2 * 8)
+    out = {
+        "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": 1, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+        "config": {"workload": f"Scotty3D Pathtracer: Cornell box + 131 072-triangle glass mesh + mirror sphere (BASELINE configs[4] on one GPU; seeded "
+                               f"procedural stand-in for the Stanford dragon, a missing blob of the reference checkout), {W}x{H}, {spp} spp per step, "
+                               f"depth {args.depth}, BVH on", "triangles": 131072, "bvh_nodes": 80127, "kernel_form": form},
+        "host_scene_build_s": build_s,
+        "camera_samples_per_s": cams / elapsed, "rays": rays, "rays_per_camera_sample": rays / max(1, cams),
+        "image_sha256_16": hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()[:16],
+        "roofline": pt_roofline(cnt, rays / steps, kernel_ms, doc, why_not,
+                                "pt_wave_kernel<.., 4, ..> + pt_compact_kernel + pt_cast_kernel (every kernel of one epoch)" if form == 4 else str(form),
+                                scratch, {"stream_kernels_ms": split,
+                                          "working_set": "2.6 MB of interior records + 6.3 MB of triangles (+ 6.3 MB normals): L2 (4 MiB per XCD) / Infinity Cache resident"}),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt, budget_s=8.0)
+    pt.close()
+    return out
 
 
 def main():
@@ -201,7 +336,9 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_lambertian"])
+    ap.add_argument("--scene", default="cbox", choices=["cbox", "cbox_lambertian", "cfg5"],
+                    help="cfg5 = BASELINE configs[4] stand-in: the Cornell box with a 131 072-triangle glass mesh (the dragon is a missing blob)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the extra object that measures BASELINE configs[4]'s workload")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
@@ -235,12 +372,15 @@ def main():
 
     W = H = args.size
     spp = args.spp_per_step
-    scene = scenes.cornell_box(args.scene)
+    scene = scenes.cornell_with_mesh(7, "glass") if args.scene == "cfg5" else scenes.cornell_box(args.scene)
     pt = srt_amd.Pathtracer(local_rank)
     pt.set_params(W, H, spp * args.steps, args.depth, True)
     pt.build_scene(scene)
     pt.set_camera(scene["camera"])
     pt.set_tiling(32, 32, rank, world)
+    form = pt.kernel_form()
+    kernel_name = {0: "pt_wave_kernel", 1: "pt_wave_kernel", 2: "pt_wave_kernel", 3: "pt_wave_kernel<.., 3, ..> + pt_cast_kernel",
+                   4: "pt_wave_kernel<.., 4, ..> + pt_cast_kernel", -1: "pt_unit_kernel", -2: "pt_epoch_kernel"}[form]
     local_tiles, per_rank, fpt = pt.tile_info()
     shard = TileShard(W, H, 32, 32, rank, world)
     assert (local_tiles, per_rank, fpt) == (len(shard.local), shard.tiles_per_rank, shard.floats_per_tile)
@@ -250,7 +390,7 @@ def main():
     # leaves idle (a 1/8 image shard: 8.9 -> 8.2 ms per step, tools/overlap_bench.py).  Each stream has its own tile /
     # gather / image buffers (and the library keeps one set of epoch scratch per stream); the running-mean
     # accumulate is order dependent, so it waits for the previous step's accumulate through an event.
-    nstreams = 1 if (rehearse or args.no_overlap) else 2
+    nstreams = 1 if (rehearse or args.no_overlap or form >= 3) else 2     # (the streamed forms fill the GPU by themselves)
     streams = [torch.cuda.current_stream()] if nstreams == 1 else [torch.cuda.Stream(device=dev) for _ in range(2)]
     tiles = [torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev) for _ in range(nstreams)]
     gathered = [torch.zeros(world * per_rank * fpt, dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
@@ -309,6 +449,8 @@ def main():
 
     rays, cams = pt.ray_count()
     pt.kernel_time(enable=True)
+    if form >= 3:
+        pt.stream_times(enable=True)
     # the dominant kernel on its own (HIP events inside the library, on the launch stream): two launches after the
     # timed region, nothing else in flight - inside the timed region consecutive launches overlap by design
     for j in range(2):
@@ -316,6 +458,11 @@ def main():
     torch.cuda.synchronize()
     wave_ms_total, wave_launches = pt.kernel_time(enable=False)
     kernel_ms = wave_ms_total / max(1, wave_launches)          # agrees with rocprofv3 AverageNs of a non-overlapped run
+    stream_split = None
+    if form >= 3:                                              # the streamed forms: the epoch's kernels one by one
+        ms3, gens = pt.stream_times(enable=False)
+        stream_split = {k: v / 2 for k, v in ms3.items()}
+        stream_split["generations_enqueued_per_step"] = gens // 2
     pt.ray_count(reset=True)
     epoch_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))  # per step, overlapped
     if world > 1:
@@ -373,20 +520,28 @@ def main():
         ss = rng.integers(0, spp * args.steps, n).astype(np.uint32)
         pt.trace_samples(args.seed, xs, ys, ss)
         cnt = pt.counters()
-        bpr = bytes_per_ray(cnt)
         rays_per_launch_rank0 = rays / args.steps
-        achieved = bpr * rays_per_launch_rank0 / (kernel_ms * 1e-3) / 1e9
+        cams_per_launch_rank0 = cams / args.steps
         mean_radiance = main_mean
         image_sha = main_sha[:16]
-        traffic, prof_doc = traffic_bytes(W, spp, world)
+        prof_doc, why_not = profile_doc(args.scene, W, spp, world)
+        # ray state that goes through memory per launch (SURVEY.md 8(d)'s last term): a 32-byte record per shaded bounce,
+        # written once and read once, and one 16-byte store per sample (read again by the ordered reduction)
+        bounces = max(0.0, (rays_per_launch_rank0 - cams_per_launch_rank0) / 3.0)
+        scratch = 64.0 * bounces + 32.0 * cams_per_launch_rank0
+        if form >= 3:    # the streamed forms also keep the path state, the rays / walk requests and the hits in memory between two kernels
+            scratch += (rays_per_launch_rank0 / 2.8) * 2 * 24 * 4 + rays_per_launch_rank0 * (2 * 36 + 2 * 8)
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"Scotty3D Pathtracer: Cornell box ({args.scene}: area light + MIS"
-                            f"{', mirror + glass spheres' if args.scene == 'cbox' else ''}), {W}x{H}, {spp} spp per step "
-                            f"({args.steps} steps = {spp * args.steps} spp; 32 steps = BASELINE configs[3] 2048 spp), depth {args.depth}, BVH on",
+                "workload": (f"Scotty3D Pathtracer: Cornell box + 131 072-triangle glass mesh + mirror sphere (BASELINE configs[4]; seeded procedural "
+                             f"stand-in for the Stanford dragon, a missing blob of the reference checkout), {W}x{H}, {spp} spp per step "
+                             f"({args.steps} steps = {spp * args.steps} spp), depth {args.depth}, BVH on") if args.scene == "cfg5" else
+                            (f"Scotty3D Pathtracer: Cornell box ({args.scene}: area light + MIS"
+                             f"{', mirror + glass spheres' if args.scene == 'cbox' else ''}), {W}x{H}, {spp} spp per step "
+                             f"({args.steps} steps = {spp * args.steps} spp; 32 steps = BASELINE configs[3] 2048 spp), depth {args.depth}, BVH on"),
                 "tiles": "32x32 round-robin over ranks", "collective": "one RCCL gather of tile radiance per step" if world > 1 else "none (1 GPU)",
                 "seed": args.seed,
             },
@@ -394,22 +549,20 @@ def main():
             "rays_per_camera_sample": total_rays / max(1, total_cams),
             "rays_counted": "every scene.hit the reference performs (no ray is elided)",
             "mean_radiance": mean_radiance, "image_sha256_16": image_sha,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "pt_wave_kernel", "kernel_ms": kernel_ms,
+            "roofline": pt_roofline(cnt, rays_per_launch_rank0, kernel_ms, prof_doc, why_not, kernel_name, scratch, {
                 "kernel_ms_max_over_ranks": kernel_ms_max, "kernel_launches": wave_launches,
+                "kernel_ms_is": "one launch on its own, after the timed region (the streamed forms: every kernel of one epoch); "
+                                "`ms_per_step` is wall time of the timed region / steps, where consecutive launches overlap on two streams",
                 "step_span_ms_on_its_stream": epoch_ms,   # start-to-end of a step on its own stream; the other stream's step shares the GPU meanwhile
-                "algorithmic_bytes_per_ray": bpr,
-                "per_ray": {k: cnt[k] / cnt["rays"] for k in cnt if k != "rays"},
-                "note": "scene (~3 KB) is cache resident by construction; achieved = algorithmic bytes / kernel time (SURVEY.md §8d); "
-                        "the binding resource is vector-instruction issue, see `valu`",
-                "valu": valu_utilisation(prof_doc, kernel_ms),
-            },
+                "stream_kernels_ms": stream_split,
+            }),
         }
         if elision is not None:
             out["dead_ray_elision"] = elision
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt)
+        if not args.no_cfg5 and world == 1 and args.scene != "cfg5":
+            out["cfg5"] = cfg5_bench(local_rank, args)
         if not args.no_raster and world == 1:
             out["raster"] = raster_bench(local_rank)
         print(json.dumps(out), flush=True)

@@ -147,9 +147,14 @@ int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, con
  * per sample), 1 = per-lane kernel, one lane per pixel (any scene), 2 = persistent wave kernel with wave-uniform
  * sweeps (<= 16 objects; fails otherwise), 3 = the same with in-kernel section stamps (diagnostic build, slower),
  * 4 = per-lane kernel, one lane per sample (any scene), 5 = persistent wave kernel with the flattened per-lane
- * walk of both tree levels (<= 31 objects; fails otherwise; srt_pt_hit then also goes through that walk).  All
+ * walk of both tree levels (<= 31 objects; fails otherwise; srt_pt_hit then also goes through that walk),
+ * 6 = streamed form (any number of objects): a logic kernel per generation (consume hits, shade, refill, emit rays) and a
+ * persistent ray-cast kernel that walks one ray per lane through both tree levels with LDS stacks and pulls rays from a
+ * dense queue; 7 = streamed sweeps (<= 16 objects of which 1..4 meshes with a real BVH<Triangle>: BASELINE configs[4]): the
+ * wave-uniform sweeps stay in the logic kernel, only the walks of those meshes are queued to the ray-cast kernel.
+ * Automatic picks 7 where it applies, 6 for scenes the sweeps do not take.  All
  * produce bit-identical images; the switch exists for A/B tests and profiling. */
-int srt_pt_set_kernel(srt_pt* pt, int mode);
+int srt_pt_set_kernel(srt_pt* pt, int mode);   /* modes 6 and 7: see below */
 /* Mode 3 only: shader-clock cycles summed over waves per loop section
  * {refill, top-down sweep, leaf objects, combine, finish-direct, shade, terminate, 0}. */
 int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset);
@@ -159,6 +164,15 @@ int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset);
  * Returns the sum over the launches recorded since the previous call (waits for them), then switches
  * recording on (enable != 0) or off.  Off by default. */
 int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launches);
+
+/* Streamed forms (kernel modes 6, 7) only: device time of the three kernels of a generation - {logic, compaction, ray cast} - summed
+ * over every generation launched since the previous call (HIP events around each launch, on the launch stream; waits for them),
+ * and the number of generations enqueued; then switches recording on (enable != 0) or off.  Off by default: a diagnostic. */
+int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[3], uint64_t* generations);
+/* Which form render_epoch* takes for the committed scene under the current kernel mode: 0 persistent wave kernel with sweeps,
+ * 1 the same with inline BVH<Triangle> walks, 2 persistent waves with the flattened walk, 3 streamed (every ray through the
+ * ray-cast kernel), 4 streamed sweeps (BVH<Triangle> walks queued), -1 lane per sample, -2 lane per pixel. */
+int srt_pt_kernel_form(srt_pt* pt, int* form);
 
 /* Rays (scene.hit calls) and camera samples traced by this context since the last reset. */
 int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int reset);

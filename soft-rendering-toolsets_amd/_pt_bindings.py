@@ -42,6 +42,8 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_section_cycles.argtypes = [c_void_p, c_void_p, c_int]
     lib.srt_pt_kernel_time.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]
     lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
+    lib.srt_pt_stream_times.argtypes = [c_void_p, c_int, c_void_p, POINTER(c_uint64)]
+    lib.srt_pt_kernel_form.argtypes = [c_void_p, POINTER(c_int)]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_dump_bvh.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -244,6 +246,20 @@ class Pathtracer:
         ms, n = ctypes.c_double(), c_uint64()
         self._check(self._lib, self._lib.srt_pt_kernel_time(self._ctx, int(enable), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def stream_times(self, enable: bool = True):
+        """({"logic_ms", "compact_ms", "cast_ms"}, generations) of the streamed forms since the previous call; then recording on/off."""
+        ms = np.zeros(3, np.float64)
+        g = c_uint64()
+        self._check(self._lib, self._lib.srt_pt_stream_times(self._ctx, int(enable), _p(ms), ctypes.byref(g)))
+        return {"logic_ms": float(ms[0]), "compact_ms": float(ms[1]), "cast_ms": float(ms[2])}, int(g.value)
+
+    def kernel_form(self) -> int:
+        """Form render_epoch takes for the committed scene: 0 / 1 persistent sweeps (1: inline mesh walks), 2 flattened walk,
+        3 streamed, 4 streamed sweeps, -1 lane per sample, -2 lane per pixel."""
+        f = c_int()
+        self._check(self._lib, self._lib.srt_pt_kernel_form(self._ctx, ctypes.byref(f)))
+        return int(f.value)
 
     def ray_count(self, reset: bool = False):
         """(rays, camera_samples) traced by render_epoch* since the last reset (synchronizes the device)."""

@@ -300,6 +300,10 @@ struct srt_pt {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;   // pending (recorded, not yet read)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
+  // srt_pt_stream_times: per-kernel event pairs of the streamed form {logic, compaction, ray cast}
+  bool stream_timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> stream_timed[3];
+  uint64_t stream_generations = 0;
 };
 
 namespace {
@@ -454,6 +458,21 @@ int time_begin(srt_pt* pt, hipStream_t s) {
   else { SRT_HIP(hipEventCreate(&ev.first)); SRT_HIP(hipEventCreate(&ev.second)); }
   pt->timed.push_back(ev);
   SRT_HIP(hipEventRecord(ev.first, s));
+  return SRT_OK;
+}
+// Brackets for one kernel of the streamed form (srt_pt_stream_times; diagnostic, off by default).
+int stream_time_begin(srt_pt* pt, hipStream_t s, int which) {
+  if (!pt->stream_timing) return SRT_OK;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!pt->spare.empty()) { ev = pt->spare.back(); pt->spare.pop_back(); }
+  else { SRT_HIP(hipEventCreate(&ev.first)); SRT_HIP(hipEventCreate(&ev.second)); }
+  pt->stream_timed[which].push_back(ev);
+  SRT_HIP(hipEventRecord(ev.first, s));
+  return SRT_OK;
+}
+int stream_time_end(srt_pt* pt, hipStream_t s, int which) {
+  if (!pt->stream_timing) return SRT_OK;
+  SRT_HIP(hipEventRecord(pt->stream_timed[which].back().second, s));
   return SRT_OK;
 }
 int time_end(srt_pt* pt, hipStream_t s) {
@@ -667,14 +686,19 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   pt_wave_kernel<false, TRAV_, DL_, NR_><<<lgrid, lblock, logic_lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes,         \
                                                                           DS.lights, DS.light_tris, DS.materials, DS.wave_tlas,    \
                                                                           DS.blas_recs, P.records, P.sample_out)
+        if ((st = stream_time_begin(pt, s, 0)) != SRT_OK) return st;
         if (trav == 4) { if (two) SRT_LAUNCH_LOGIC(4, false, 2); else if (dl) SRT_LAUNCH_LOGIC(4, true, 3); else SRT_LAUNCH_LOGIC(4, false, 3); }
         else { if (two) SRT_LAUNCH_LOGIC(3, false, 2); else if (dl) SRT_LAUNCH_LOGIC(3, true, 3); else SRT_LAUNCH_LOGIC(3, false, 3); }
 #undef SRT_LAUNCH_LOGIC
+        if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 1)) != SRT_OK) return st;
         pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id);
+        if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
         C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
         if (pt->d_cast_stats) pt_cast_kernel<true><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
         else pt_cast_kernel<false><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
+        if ((st = stream_time_end(pt, s, 2)) != SRT_OK) return st;
       }
+      if (pt->stream_timing) pt->stream_generations += gens;
       pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
@@ -765,7 +789,7 @@ int srt_pt_destroy(srt_pt* pt) {
       (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id);
       (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc); (void)hipFree(kv.second.d_block_counters);
     }
-    for (auto& v : {&pt->timed, &pt->spare})
+    for (auto& v : {&pt->timed, &pt->spare, &pt->stream_timed[0], &pt->stream_timed[1], &pt->stream_timed[2]})
       for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipStreamDestroy(pt->stream);
   }
@@ -1082,6 +1106,35 @@ int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launc
   pt->timing = enable != 0;
   if (total_ms) *total_ms = sum;
   if (launches) *launches = n;
+  return SRT_OK;
+}
+
+int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[3], uint64_t* generations) {
+  int st = need_device(pt, "srt_pt_stream_times");
+  if (st != SRT_OK) return st;
+  for (int k = 0; k < 3; k++) {
+    double sum = 0.0;
+    for (auto& ev : pt->stream_timed[k]) {
+      SRT_HIP(hipEventSynchronize(ev.second));
+      float ms = 0.f;
+      SRT_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+      sum += ms;
+      pt->spare.push_back(ev);
+    }
+    pt->stream_timed[k].clear();
+    if (ms_out) ms_out[k] = sum;
+  }
+  if (generations) *generations = pt->stream_generations;
+  pt->stream_generations = 0;
+  pt->stream_timing = enable != 0;
+  return SRT_OK;
+}
+
+int srt_pt_kernel_form(srt_pt* pt, int* form) {
+  if (!pt || !form) return srt::fail(SRT_ERR_INVALID, "srt_pt_kernel_form: NULL argument");
+  if (!pt->committed) return srt::fail(SRT_ERR_STATE, "srt_pt_kernel_form before srt_pt_scene_commit");
+  const int t = wave_trav(pt);
+  *form = t >= 0 ? t : (pt->kernel_mode == 1 ? -2 : -1);
   return SRT_OK;
 }
 

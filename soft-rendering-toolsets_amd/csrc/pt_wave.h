@@ -49,7 +49,7 @@ constexpr uint32_t kChunk = 64;           // units (sample triples) a wave reser
 constexpr uint32_t kBurst = 3;            // camera rays per burst = samples per unit (2 in the two-ray build)
 constexpr uint32_t kMissTri = 0xFFFFFFFFu;
 constexpr uint32_t kFlatReady = 16;        // TRAV 2: lanes with a finished batch that make the wave leave the walk
-constexpr int kRecFields = 8;             // direct rgb, atten rgb, inv_pdf, discrete
+constexpr int kRecFields = 8;             // two float4 per bounce: {direct rgb, discrete} and {atten rgb, inv_pdf}
 
 struct WaveParams {
   TileMap T;
@@ -61,7 +61,8 @@ struct WaveParams {
   uint32_t total_units;      // pixels * (groups3 + singles)
   uint32_t nlanes;           // threads of the whole grid (record scratch stride)
   float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
-  float* records;            // [(level * kRecFields + f) * nlanes + lane]
+  float* records;            // float4 [(level * 2 + half) * nlanes + lane]: a bounce record is two coalesced 16-byte stores per lane
+                             // (half 0 = {direct rgb, discrete} when the bounce's direct light is known, half 1 = {atten rgb, 1/pdf} when it is shaded)
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls as the reference issues them, accumulated across launches
   unsigned long long* elided_counter;  // of those, the rays the two-ray build did not have to trace
@@ -877,8 +878,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             radiance = radiance + dA_keep;
             radiance = radiance - dA_keep;
             radiance = radiance + d6_keep;
-            float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-            rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+            reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
             sh_phase = false;
             chit = held_chit;
             d[C] = dC_keep;
@@ -915,8 +915,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           const Spec d6 = (e0 * att) * (1.0f / pdf);
           radiance = radiance + d6;                     // ((0 + direct) - direct) + d6
         }
-        float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-        rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+        reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
         chit = pack_ret(res[C], oshift);
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
@@ -945,8 +944,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             }
           }
           if (!(DL && sh_phase)) {
-            float* rec = P.records + ((size_t)(level - 1) * kRecFields) * P.nlanes + lane_global;
-            rec[0] = radiance.r; rec[(size_t)P.nlanes] = radiance.g; rec[2 * (size_t)P.nlanes] = radiance.b;
+            reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
           }
         }
         chit = pack_ret(res[C], oshift);
@@ -996,11 +994,11 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (!terminal) { need_shade = true; break; }
         Spec L = spec(0, 0, 0);
         for (int k = (int)level - 1; k >= 0; k--) {
-          const float* rec = P.records + ((size_t)k * kRecFields) * P.nlanes + lane_global;
-          const size_t st = P.nlanes;
-          const Spec dk = spec(rec[0], rec[st], rec[2 * st]);
-          const Spec ak = spec(rec[3 * st], rec[4 * st], rec[5 * st]);
-          Spec ind = (rec[7 * st] != 0.0f) ? (L * ak) : ((L * ak) * rec[6 * st]);
+          const float4 r0 = reinterpret_cast<const float4*>(P.records)[(size_t)k * 2 * P.nlanes + lane_global];
+          const float4 r1 = reinterpret_cast<const float4*>(P.records)[((size_t)k * 2 + 1) * P.nlanes + lane_global];
+          const Spec dk = spec(r0.x, r0.y, r0.z);
+          const Spec ak = spec(r1.x, r1.y, r1.z);
+          Spec ind = (r0.w != 0.0f) ? (L * ak) : ((L * ak) * r1.w);
           ind = spec(0, 0, 0) + ind;
           L = dk + ind;
         }
@@ -1064,11 +1062,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
         else s2 = scatter(m, out_dir, rng);
         const V3 world_in2 = frame_to_world(fr, s2.dir);
-        float* rec = P.records + ((size_t)level * kRecFields) * P.nlanes + lane_global;
-        const size_t st = P.nlanes;
-        rec[3 * st] = s2.atten.r; rec[4 * st] = s2.atten.g; rec[5 * st] = s2.atten.b;
-        rec[6 * st] = discrete ? 0.0f : (1.0f / pdf4);
-        rec[7 * st] = discrete ? 1.0f : 0.0f;
+        reinterpret_cast<float4*>(P.records)[((size_t)level * 2 + 1) * P.nlanes + lane_global] =
+            make_float4(s2.atten.r, s2.atten.g, s2.atten.b, discrete ? 0.0f : (1.0f / pdf4));
         level++;
         depth--;
         org = sf.position;

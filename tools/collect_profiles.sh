@@ -1,22 +1,29 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence bench.py's roofline object refers to.  Run on the GPU box from the repo root:
-#   bash tools/collect_profiles.sh <tag>          (outputs under gpurun_out/prof_<tag>/)
+# Collects the rocprofv3 evidence bench.py's roofline objects refer to.  Run on the GPU box from the repo root:
+#   bash tools/collect_profiles.sh <tag> [scene]      scene = cbox (default) | cfg5; outputs under gpurun_out/prof_<tag>/
 # Separate passes (kernel trace; FETCH_SIZE; WRITE_SIZE + L2 hit/miss; two SQ counter passes) as MI355X_MICROARCH.md prescribes:
 # counters are never combined with a trace.  tools/make_traffic.py turns the CSVs into profiles/<tag>_*.
 set -e
-tag=${1:-r01_final}
+tag=${1:-r02_final}
+scene=${2:-cbox}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
+common="--scene $scene --no-cpu-baseline --no-cfg5 --no-overlap"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" --steps 8 --warmup 1 --no-cpu-baseline --no-overlap > "$out/stats.log" 2>&1
+if [ "$scene" = cbox ]; then statsopt="--steps 8 --warmup 1"; else statsopt="--steps 2 --warmup 1 --no-raster --no-elision"; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" $statsopt $common > "$out/stats.log" 2>&1
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 "$root/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-raster --no-overlap --no-elision > "$out/fetch.log" 2>&1
+pmcopt="--steps 2 --warmup 0 --no-raster --no-elision $common"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 "$root/bench.py" $pmcopt > "$out/fetch.log" 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/write" -- python3 "$root/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-raster --no-overlap --no-elision > "$out/write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/write" -- python3 "$root/bench.py" $pmcopt > "$out/write.log" 2>&1
 echo "write pass done"
-cd "$root"
-bash tools/pmc_sq.sh "$tag" > "$out/pmc_sq.log" 2>&1      # SQ instruction counters (two more passes), outputs under gpurun_out/pmc_<tag>/
+sq=$root/gpurun_out/pmc_$tag
+rm -rf "$sq"; mkdir -p "$sq"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$sq/a" -- python3 "$root/bench.py" $pmcopt > "$sq/a.log" 2>&1
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d "$sq/b" -- python3 "$root/bench.py" $pmcopt > "$sq/b.log" 2>&1
 echo "sq passes done"
-python3 tools/make_traffic.py "$out" "$tag" "$root/gpurun_out/pmc_$tag"
+cd "$root"
+python3 tools/make_traffic.py "$out" "$tag" "$sq" "$scene" 4
