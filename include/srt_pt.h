@@ -206,7 +206,8 @@ long srt_pt_dump_bvh(srt_pt* pt, int which, float* boxes, uint32_t* links, size_
  * (unsigned char)round(to_srgb(1 - exp(-c * exposure)) * 255), alpha 255.  exposure must be positive (the reference
  * substitutes the image's own exposure for e <= 0; the caller passes that value).  Bit-identical to the reference built
  * against glibc 2.35 on an x86-64 host with FMA.  The _device form takes device pointers (rgba 4-byte aligned) and
- * enqueues on `stream` (NULL: the context's stream) without synchronising. */
+ * enqueues on `stream` exactly as the other *_device calls do (hipStream_t; NULL = the HIP default stream) without
+ * synchronising: a tone map enqueued behind srt_pt_accumulate_device on the same stream sees that accumulate's result. */
 int srt_pt_tonemap(srt_pt* pt, const float* rgb, uint32_t width, uint32_t height, float exposure, uint8_t* rgba_out);
 int srt_pt_tonemap_device(srt_pt* pt, void* stream, const float* d_rgb, uint32_t width, uint32_t height, float exposure,
                           uint8_t* d_rgba);

@@ -325,7 +325,7 @@ class Pathtracer:
         return out
 
     def tonemap_device(self, d_rgb_ptr: int, w: int, h: int, exposure: float, d_rgba_ptr: int, stream: int = 0) -> None:
-        self._check(self._lib, self._lib.srt_pt_tonemap_device(self._ctx, stream or None, d_rgb_ptr, w, h, float(exposure), d_rgba_ptr))
+        self._check(self._lib, self._lib.srt_pt_tonemap_device(self._ctx, c_void_p(stream), d_rgb_ptr, w, h, float(exposure), d_rgba_ptr))
 
     def math_exp(self, x):
         x = _f32(x)

@@ -1311,7 +1311,7 @@ int srt_pt_tonemap_device(srt_pt* pt, void* stream, const float* d_rgb, uint32_t
   if ((reinterpret_cast<uintptr_t>(d_rgba) & 3u) != 0) return srt::fail(SRT_ERR_INVALID, "srt_pt_tonemap_device: rgba must be 4-byte aligned");
   const size_t px = (size_t)width * height;
   if (!px) return SRT_OK;
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : pt->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);      // exactly the caller's stream; NULL is the HIP default stream, as for every *_device call
   pt_tonemap_kernel<<<dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s>>>(d_rgb, width, height, exposure, reinterpret_cast<uint32_t*>(d_rgba));
   SRT_HIP(hipGetLastError());
   return SRT_OK;
@@ -1330,7 +1330,7 @@ int srt_pt_tonemap(srt_pt* pt, const float* rgb, uint32_t width, uint32_t height
   SRT_HIP(tmp.alloc(&d_out, px * 4));
   st = SRT_OK;
   if (hipMemcpyAsync(d_in, rgb, px * 12, hipMemcpyHostToDevice, pt->stream) != hipSuccess) st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: upload failed");
-  if (st == SRT_OK) st = srt_pt_tonemap_device(pt, nullptr, d_in, width, height, exposure, d_out);
+  if (st == SRT_OK) st = srt_pt_tonemap_device(pt, (void*)pt->stream, d_in, width, height, exposure, d_out);
   if (st == SRT_OK && (hipMemcpyAsync(rgba_out, d_out, px * 4, hipMemcpyDeviceToHost, pt->stream) != hipSuccess ||
                        hipStreamSynchronize(pt->stream) != hipSuccess))
     st = srt::fail(SRT_ERR_HIP, "srt_pt_tonemap: download failed");

@@ -176,9 +176,22 @@ def test_tonemap_matches_reference_golden(srt):
     d_rgb = torch.from_numpy(rgb).cuda()
     d_out = torch.zeros((768, 1024, 4), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
-    pt.tonemap_device(d_rgb.data_ptr(), 1024, 768, 1.7, d_out.data_ptr())
-    pt.sync()
+    pt.tonemap_device(d_rgb.data_ptr(), 1024, 768, 1.7, d_out.data_ptr())     # stream 0 = the HIP default stream = torch's
     assert np.array_equal(d_out.cpu().numpy(), want)
+    # ordering on the caller's stream, no host synchronisation in between: accumulate_device then tonemap_device on one
+    # (non-default) torch stream - the tone map must see the accumulated radiance, not the buffer's previous content
+    S = torch.cuda.Stream()
+    with torch.cuda.stream(S):
+        d_acc = torch.full((768 * 1024 * 3,), 1e9, dtype=torch.float32, device="cuda")       # stale content: saturates every byte
+        d_out2 = torch.zeros((768, 1024, 4), dtype=torch.uint8, device="cuda")
+        big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+        for _ in range(4):
+            big.add_(1.0)                                                                       # keep the stream busy ahead of the pair
+        d_acc.zero_()
+        pt.accumulate_device(S.cuda_stream, d_acc.data_ptr(), d_rgb.data_ptr(), d_acc.numel(), 1)   # acc += (rgb - acc) * 1
+        pt.tonemap_device(d_acc.data_ptr(), 1024, 768, 1.7, d_out2.data_ptr(), stream=S.cuda_stream)
+    S.synchronize()
+    assert np.array_equal(d_out2.cpu().numpy(), want)
     with pytest.raises(srt.SrtError):
         pt.tonemap(rgb, 0.0)
     assert pt.tonemap(np.zeros((0, 0, 3), np.float32), 1.0).shape == (0, 0, 4)
