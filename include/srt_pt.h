@@ -193,8 +193,21 @@ int srt_pt_rays_elided(srt_pt* pt, uint64_t* elided, int reset);
  * draws_out / rays_out (nullable): RNG draws and scene.hit calls of that sample. */
 int srt_pt_trace_samples(srt_pt* pt, uint64_t seed, const uint32_t* xs, const uint32_t* ys, const uint32_t* ss,
                          size_t n, float* rgb_out, uint32_t* draws_out, uint32_t* rays_out);
-/* scene.hit for explicit rays.  out9: {hit, distance, position[3], normal[3], material} per ray (Trace). */
+/* scene.hit for explicit rays.  out9: {hit, distance, position[3], normal[3], material} per ray (Trace).  Directions need
+ * not be normalised (the particle step passes velocities): times, distances and dist_bounds follow lib/ray.h and
+ * student/bvh.inl exactly as the reference scales them. */
 int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float* bounds, size_t n, float* out9);
+/* Scene_Particles::Particle::update (student/particles.cpp:5-59) for n particles against the committed scene - the loop body of
+ * Scene_Particles::step2 (scene/particles.cpp:134-138), the second caller of Object::hit besides the path tracer (the scene
+ * it collides with is Simulate::build_scene's BVH<Object>, gui/simulate.cpp:69-99: commit the same objects).  pos / vel: 3
+ * floats per particle, age: 1, updated in place; alive[k] = update()'s return value (age > 0).  dt is one simulation step
+ * (Options::dt), radius the particle radius times Options::scale.  Spawning and removing particles stay with the caller.
+ * The reference's loop never returns when its hit_time stays <= 0; the kernel gives such a particle up after 4096 legs.
+ * Host form: synchronous.  Device form: device pointers, enqueued on `stream` (NULL = the HIP default stream). */
+int srt_pt_particles_step(srt_pt* pt, float* pos, float* vel, float* age, size_t n, float dt, float radius, uint8_t* alive);
+int srt_pt_particles_step_device(srt_pt* pt, void* stream, float* d_pos, float* d_vel, float* d_age, size_t n, float dt, float radius,
+                                 uint8_t* d_alive);
+
 /* Host-side BVH arrays after commit.  which = -1: the BVH<Object> (order = 1-based insertion index of the
  * objects in BVH primitive order); which >= 0: the BVH<Triangle> of the which-th BVH<Object> primitive
  * (order = first vertex index of each triangle in BVH primitive order).  boxes: 6 floats per node,

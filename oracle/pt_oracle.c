@@ -1318,6 +1318,52 @@ int srt_oracle_pt_hit(void* h, const float* org, const float* dir, const float* 
     return 0;
 }
 
+/* Scene_Particles::Particle::update (student/particles.cpp:5-59), the loop body of Scene_Particles::step2
+ * (scene/particles.cpp:134-138): the particle flies at constant velocity for what is left of dt, bounces off what
+ * scene.hit(Ray(pos, velocity)) reports (default bounds [0, inf], direction NOT normalised), gravity acts on the velocity
+ * after every leg.  The unqualified sqrt is the double overload.  max_iter = 0: loop like the reference (which never
+ * returns when hit_time stays <= 0); else give up after that many legs (what the device kernel does). */
+int srt_oracle_pt_particles_update(void* h, float* pos, float* vel, float* age, size_t n, float dt, float radius, unsigned char* alive,
+                                   uint32_t max_iter) {
+    const scene_t* s = (const scene_t*)h;
+    ctx_t c; memset(&c, 0, sizeof c); c.s = s;
+    const v3 acceleration = V(0.0f, -9.8f, 0.0f);
+    for (size_t k = 0; k < n; k++) {
+        v3 p = V(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
+        v3 velocity = V(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2]);
+        float remain = dt;
+        uint32_t it = 0;
+        while (remain > 0) {
+            if (max_iter && it++ >= max_iter) break;
+            ray_t r;
+            r.point = p; r.dir = velocity; r.b0 = 0.0f; r.b1 = INFINITY; r.depth = 0;
+            trace_t t = scene_hit(&c, &r);
+            float cos_t = v_dot(t.normal, v_scale(velocity, -1.0f)) / (v_norm(velocity) * v_norm(t.normal));
+            v3 surface_normal = v_divs(t.normal, v_norm(t.normal));
+            if (cos_t < 0) {
+                cos_t = (float)sqrt((double)(1 - cos_t * cos_t));
+                surface_normal = v_scale(surface_normal, -1.0f);
+            }
+            const float interval = fabsf(radius / cos_t);
+            const float hit_time = (t.distance - interval) / v_norm(r.dir);
+            if (!t.hit || hit_time > remain || cos_t == 0) {
+                p = v_add(p, v_scale(velocity, remain));
+                velocity = v_add(velocity, v_scale(acceleration, remain));
+                break;
+            }
+            p = v_sub(t.position, v_divs(v_scale(velocity, interval), v_norm(velocity)));
+            velocity = v_sub(velocity, v_scale(surface_normal, 2.0f * v_dot(velocity, surface_normal)));
+            velocity = v_add(velocity, v_scale(acceleration, hit_time));
+            remain -= hit_time;
+        }
+        age[k] -= dt;
+        alive[k] = age[k] > 0 ? 1 : 0;
+        pos[3 * k] = p.x; pos[3 * k + 1] = p.y; pos[3 * k + 2] = p.z;
+        vel[3 * k] = velocity.x; vel[3 * k + 1] = velocity.y; vel[3 * k + 2] = velocity.z;
+    }
+    return 0;
+}
+
 /* Node arrays: which = -1 the scene BVH<Object> (order[] = object ids, 1-based insertion index, in BVH
  * primitive order); which >= 0 the BVH<Triangle> of the which-th scene-BVH primitive (order[] = first
  * vertex index of each triangle in BVH primitive order). */

@@ -42,6 +42,7 @@
 
 // compiled with -fno-access-control (this translation unit only) to reach private members
 #include "rays/pathtracer.h"
+#include "scene/particles.h"
 #include "rays/samplers.h"
 #include "util/rand.h"
 #include "gui/widgets.h"
@@ -344,6 +345,23 @@ int ref_pt_hit(void* h, const float* org, const float* dir, const float* bounds,
     o[2] = t.position.x; o[3] = t.position.y; o[4] = t.position.z;
     o[5] = t.normal.x; o[6] = t.normal.y; o[7] = t.normal.z;
     o[8] = (float)t.material;
+  }
+  return 0;
+}
+
+// Scene_Particles::Particle::update (student/particles.cpp:5-59) for n particles against this scene - the loop body of
+// Scene_Particles::step2 (scene/particles.cpp:134-138).  pos / vel: 3 floats per particle, age: 1; alive[k] = update()'s verdict.
+int ref_pt_particles_update(void* h, float* pos, float* vel, float* age, size_t n, float dt, float radius, unsigned char* alive) {
+  RefPT* r = (RefPT*)h;
+  for (size_t k = 0; k < n; k++) {
+    Scene_Particles::Particle p;
+    p.pos = Vec3(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
+    p.velocity = Vec3(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2]);
+    p.age = age[k];
+    alive[k] = p.update(r->pt->scene, dt, radius) ? 1 : 0;
+    pos[3 * k] = p.pos.x; pos[3 * k + 1] = p.pos.y; pos[3 * k + 2] = p.pos.z;
+    vel[3 * k] = p.velocity.x; vel[3 * k + 1] = p.velocity.y; vel[3 * k + 2] = p.velocity.z;
+    age[k] = p.age;
   }
   return 0;
 }

@@ -46,6 +46,8 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_kernel_form.argtypes = [c_void_p, POINTER(c_int)]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.srt_pt_particles_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]
+    lib.srt_pt_particles_step_device.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]
     lib.srt_pt_dump_bvh.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.srt_pt_dump_bvh.restype = c_long
     lib.srt_pt_counters.argtypes = [c_void_p, c_void_p]
@@ -285,6 +287,13 @@ class Pathtracer:
         out = np.zeros((len(org), 9), np.float32)
         self._check(self._lib, self._lib.srt_pt_hit(self._ctx, _p(org), _p(dirs), _p(bounds), len(org), _p(out)))
         return out
+
+    def particles_step(self, pos, vel, age, dt: float, radius: float):
+        """Scene_Particles::Particle::update for every particle (scene/particles.cpp:134-138): returns (pos, vel, age, alive)."""
+        pos, vel, age = _f32(pos).copy(), _f32(vel).copy(), _f32(age).copy()
+        alive = np.zeros(len(age), np.uint8)
+        self._check(self._lib, self._lib.srt_pt_particles_step(self._ctx, _p(pos), _p(vel), _p(age), len(age), float(dt), float(radius), _p(alive)))
+        return pos, vel, age, alive
 
     def dump_bvh(self, which: int, cap: int = 1 << 22):
         boxes = np.zeros((cap, 6), np.float32)

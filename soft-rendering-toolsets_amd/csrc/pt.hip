@@ -156,6 +156,52 @@ __global__ void pt_hit_kernel(DScene S, const float* __restrict__ org, const flo
   }
 }
 
+// Scene_Particles::Particle::update (student/particles.cpp:5-59), one lane per particle: the second caller of Object::hit
+// (SURVEY.md 8(f)-4).  The particle flies at constant velocity for what is left of dt, bounces off what
+// scene.hit(Ray(pos, velocity)) reports - default bounds [0, inf], the direction is the velocity, NOT normalised - and
+// gravity acts on the velocity after every leg.  The reference's loop does not return when hit_time stays <= 0; a lane
+// gives up after kParticleMaxLegs legs.
+constexpr uint32_t kParticleMaxLegs = 4096;
+__global__ __launch_bounds__(64) void pt_particles_kernel(DScene S, float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ age,
+                                                          uint32_t n, float dt, float radius, uint8_t* __restrict__ alive) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  V3 p = v3(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]);
+  V3 velocity = v3(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2]);
+  const V3 acceleration = v3(0.0f, -9.8f, 0.0f);
+  float remain = dt;
+  Counters cnt;
+  for (uint32_t leg = 0; remain > 0 && leg < kParticleMaxLegs; leg++) {
+    Ray r;
+    r.o = p; r.d = velocity; r.b0 = 0.0f; r.b1 = __uint_as_float(0x7f800000u);
+    const Hit h = scene_hit<false>(S, r, cnt);
+    V3 t_normal = v3(0, 0, 0), t_position = v3(0, 0, 0);       // a Trace without a hit is all zeros (rays/trace.h)
+    if (h.hit) { const Surface sf = surface_of(S, h, r); t_normal = sf.normal; t_position = sf.position; }
+    float cos_t = dot(t_normal, velocity * -1.0f) / (norm(velocity) * norm(t_normal));
+    V3 surface_normal = t_normal / norm(t_normal);
+    if (cos_t < 0) {
+      cos_t = (float)sqrt((double)(1 - cos_t * cos_t));          // unqualified sqrt: the double overload
+      surface_normal = surface_normal * -1.0f;
+    }
+    const float interval = fabsf(radius / cos_t);
+    const float hit_time = (h.dist - interval) / norm(r.d);
+    if (!h.hit || hit_time > remain || cos_t == 0) {
+      p = p + velocity * remain;
+      velocity = velocity + acceleration * remain;
+      break;
+    }
+    p = t_position - (velocity * interval) / norm(velocity);
+    velocity = velocity - surface_normal * (2.0f * dot(velocity, surface_normal));
+    velocity = velocity + acceleration * hit_time;
+    remain -= hit_time;
+  }
+  const float a = age[k] - dt;
+  age[k] = a;
+  alive[k] = a > 0 ? 1 : 0;
+  pos[3 * k] = p.x; pos[3 * k + 1] = p.y; pos[3 * k + 2] = p.z;
+  vel[3 * k] = velocity.x; vel[3 * k + 1] = velocity.y; vel[3 * k + 2] = velocity.z;
+}
+
 __global__ void pt_untile_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t tiles_per_rank,
                                  const float* __restrict__ gathered, float* __restrict__ image) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1221,6 +1267,42 @@ int srt_pt_hit(srt_pt* pt, const float* origins, const float* dirs, const float*
   }
   SRT_HIP(hipGetLastError());
   SRT_HIP(hipMemcpyAsync(out9, dout, n * 36, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipStreamSynchronize(pt->stream));
+  return SRT_OK;
+}
+
+int srt_pt_particles_step_device(srt_pt* pt, void* stream, float* d_pos, float* d_vel, float* d_age, size_t n, float dt, float radius,
+                                 uint8_t* d_alive) {
+  int st = need_device(pt, "srt_pt_particles_step_device");
+  if (st != SRT_OK) return st;
+  if (!pt->committed) return srt::fail(SRT_ERR_STATE, "srt_pt_particles_step before srt_pt_scene_commit");
+  if (n == 0) return SRT_OK;
+  if (!d_pos || !d_vel || !d_age || !d_alive) return srt::fail(SRT_ERR_INVALID, "srt_pt_particles_step: NULL argument");
+  if (n > 0x7fffffffull) return srt::fail(SRT_ERR_UNSUPPORTED, "too many particles in one call");
+  pt_particles_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream>>>(device_scene(pt), d_pos, d_vel, d_age, (uint32_t)n, dt,
+                                                                                           radius, d_alive);
+  SRT_HIP(hipGetLastError());
+  return SRT_OK;
+}
+
+int srt_pt_particles_step(srt_pt* pt, float* pos, float* vel, float* age, size_t n, float dt, float radius, uint8_t* alive) {
+  int st = need_device(pt, "srt_pt_particles_step");
+  if (st != SRT_OK) return st;
+  if (n == 0) return SRT_OK;
+  if (!pos || !vel || !age || !alive) return srt::fail(SRT_ERR_INVALID, "srt_pt_particles_step: NULL argument");
+  float *dp = nullptr, *dv = nullptr, *da = nullptr;
+  uint8_t* dl = nullptr;
+  srt::DeviceScratch tmp;
+  SRT_HIP(tmp.alloc(&dp, n * 12)); SRT_HIP(tmp.alloc(&dv, n * 12)); SRT_HIP(tmp.alloc(&da, n * 4)); SRT_HIP(tmp.alloc(&dl, n));
+  SRT_HIP(hipMemcpyAsync(dp, pos, n * 12, hipMemcpyHostToDevice, pt->stream));
+  SRT_HIP(hipMemcpyAsync(dv, vel, n * 12, hipMemcpyHostToDevice, pt->stream));
+  SRT_HIP(hipMemcpyAsync(da, age, n * 4, hipMemcpyHostToDevice, pt->stream));
+  st = srt_pt_particles_step_device(pt, (void*)pt->stream, dp, dv, da, n, dt, radius, dl);
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipMemcpyAsync(pos, dp, n * 12, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipMemcpyAsync(vel, dv, n * 12, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipMemcpyAsync(age, da, n * 4, hipMemcpyDeviceToHost, pt->stream));
+  SRT_HIP(hipMemcpyAsync(alive, dl, n, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   return SRT_OK;
 }

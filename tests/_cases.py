@@ -285,6 +285,35 @@ def random_rays(seed, n):
     return org, d.astype(np.float32), b
 
 
+def particle_cloud(seed, n):
+    """Particles as Scene_Particles emits them (scene/particles.cpp:143-159), scattered through the Cornell box: speeds up to the
+    default 25 units / s (several bounces per 10 ms step near a wall), some slow ones, some resting on the floor or sitting
+    closer to a wall than their radius (negative hit_time), some about to die.  Returns (pos, vel, age)."""
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((n, 3)) * [0.9, 0.9, 0.9] + [-0.45, 0.05, -0.45]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    speed = np.exp(rng.uniform(np.log(0.05), np.log(25.0), n))
+    vel = (d * speed[:, None]).astype(np.float32)
+    k = n // 16
+    pos[:k, 1] = np.float32(0.011)                                 # just above the floor, moving down: hit inside the radius
+    vel[:k, 1] = -np.abs(vel[:k, 1])
+    vel[k:2 * k] = 0.0                                             # at rest: the ray has a zero direction
+    vel[2 * k:3 * k, 0] = 0.0; vel[2 * k:3 * k, 2] = 0.0           # straight up / down (axis-aligned: 1/dir = inf in BBox::hit)
+    age = rng.uniform(-0.005, 0.5, n).astype(np.float32)
+    return pos, vel, age
+
+
+def unnormalised_rays(seed, n):
+    """Rays as Particle::update sends them: Ray() default bounds [0, inf] and dir = a velocity (norm 0.01 .. 30)."""
+    org, d, b = random_rays(seed, n)
+    rng = np.random.default_rng(seed + 1)
+    d = (d * np.exp(rng.uniform(np.log(0.01), np.log(30.0), (n, 1)))).astype(np.float32)
+    b = np.zeros((n, 2), np.float32)
+    b[:, 1] = np.inf
+    return org, d, b
+
+
 def image_stream(seed, w, h):
     """(prims, [level-0 textures]) with image records among translucent triangles: a big magnified image, images
     hanging over every border (negative coordinates fold two loop values onto sample column / row 0), one minified

@@ -317,6 +317,14 @@ class RefPT(_SceneFeeder):
         assert self.lib.ref_pt_hit(self.h_, P(org), P(dirs), P(bounds), ctypes.c_size_t(len(org)), P(out)) == 0
         return out
 
+    def particles_update(self, pos, vel, age, dt, radius):
+        """Scene_Particles::Particle::update of the reference for every particle: (pos, vel, age, alive)."""
+        pos, vel, age = _f32(pos).copy(), _f32(vel).copy(), _f32(age).copy()
+        alive = np.zeros(len(age), np.uint8)
+        assert self.lib.ref_pt_particles_update(self.h_, P(pos), P(vel), P(age), ctypes.c_size_t(len(age)), ctypes.c_float(dt),
+                                                ctypes.c_float(radius), P(alive)) == 0
+        return pos, vel, age, alive
+
     def dump_bvh(self, which, cap=1 << 22):
         boxes = np.zeros((cap, 6), np.float32)
         links = np.zeros((cap, 4), np.uint32)
@@ -397,6 +405,13 @@ class OraclePT(_SceneFeeder):
         out = np.zeros((len(org), 9), np.float32)
         assert self.lib.srt_oracle_pt_hit(self.h_, P(org), P(dirs), P(bounds), ctypes.c_size_t(len(org)), P(out)) == 0
         return out
+
+    def particles_update(self, pos, vel, age, dt, radius, max_iter=4096):
+        pos, vel, age = _f32(pos).copy(), _f32(vel).copy(), _f32(age).copy()
+        alive = np.zeros(len(age), np.uint8)
+        assert self.lib.srt_oracle_pt_particles_update(self.h_, P(pos), P(vel), P(age), ctypes.c_size_t(len(age)), ctypes.c_float(dt),
+                                                       ctypes.c_float(radius), P(alive), ctypes.c_uint32(max_iter)) == 0
+        return pos, vel, age, alive
 
     def dump_bvh(self, which, cap=1 << 22):
         boxes = np.zeros((cap, 6), np.float32)

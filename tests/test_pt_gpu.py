@@ -300,6 +300,40 @@ def test_many_objects(srt):
     pt.close()
 
 
+def test_particle_step_and_unnormalised_rays(srt):
+    """srt_pt_particles_step (Scene_Particles::Particle::update on the device, SURVEY.md 8(f)-4) against the reference-built
+    fixture over three steps and against the oracle on a larger cloud in the 74-object particle scene; srt_pt_hit with the rays
+    the step sends: un-normalised directions, bounds [0, inf]."""
+    from _cases import particle_cloud, unnormalised_rays
+
+    g = np.load(os.path.join(H.GOLDEN, "particles_cbox_blob512.npz"))
+    scene = pt_scene(str(g["scene"]))
+    assert scene_digest(scene) == str(g["scene_sha256"])
+    seed, n, steps = (int(v) for v in g["meta"])
+    pt = make_pt(srt, scene, 8, 8, 8, True)
+    pos, vel, age = particle_cloud(seed, n)
+    for s in range(steps):
+        pos, vel, age, alive = pt.particles_step(pos, vel, age, float(g["dt"]), float(g["radius"]))
+        assert bits_equal(pos, g[f"pos{s}"]) and bits_equal(vel, g[f"vel{s}"]) and bits_equal(age, g[f"age{s}"]), f"step {s}"
+        assert np.array_equal(alive, g[f"alive{s}"])
+    org, d, b = unnormalised_rays(seed + 7, 1024)
+    assert bits_equal(pt.hit(org, d, b), g["hits_unnormalised"]), "scene.hit with un-normalised directions differs from the reference"
+    pt.set_kernel(5)
+    assert bits_equal(pt.hit(org, d, b), g["hits_unnormalised"])
+    pt.close()
+    scene = pt_scene("cbox_particles")
+    pt = make_pt(srt, scene, 8, 8, 8, True)
+    o = H.OraclePT(scene, 8, 8, 8, True)
+    pos, vel, age = particle_cloud(99, 50000)
+    for s in range(2):
+        want = o.particles_update(pos, vel, age, 0.01, 0.015)
+        got = pt.particles_step(pos, vel, age, 0.01, 0.015)
+        assert all(bits_equal(x, y) for x, y in zip(got[:3], want[:3])) and np.array_equal(got[3], want[3]), f"step {s}"
+        pos, vel, age = got[:3]
+    assert pt.particles_step(pos[:0], vel[:0], age[:0], 0.01, 0.015)[3].shape == (0,)
+    pt.close()
+
+
 def test_emissive_sphere(srt):
     """An emissive analytic sphere (intersected as a sphere, sampled through its mesh approximation) on every kernel."""
     scene = pt_scene("cbox_spherelight")

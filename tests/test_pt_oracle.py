@@ -57,6 +57,32 @@ def test_oracle_matches_reference_golden(path, math_mode):
         assert bits_equal(o2.epoch(seed, base, spp), g["epoch"]), "epoch image differs from the reference"
 
 
+def test_particle_step_matches_reference_golden():
+    """Scene_Particles::Particle::update (SURVEY.md 8(f)-4) as restated by the oracle against the states the reference produced
+    over three steps (tests/golden/make_particles_golden.py), NaN positions of the particles at rest included; and scene.hit
+    for un-normalised directions with the default [0, inf] bounds, as the step sends them."""
+    from _cases import particle_cloud, unnormalised_rays
+
+    g = np.load(os.path.join(H.GOLDEN, "particles_cbox_blob512.npz"))
+    scene = pt_scene(str(g["scene"]))
+    assert scene_digest(scene) == str(g["scene_sha256"])
+    seed, n, steps = (int(v) for v in g["meta"])
+    o = H.OraclePT(scene, 8, 8, 8, True)
+    pos, vel, age = particle_cloud(seed, n)
+    for s in range(steps):
+        pos, vel, age, alive = o.particles_update(pos, vel, age, float(g["dt"]), float(g["radius"]), max_iter=0)
+        assert bits_equal(pos, g[f"pos{s}"]) and bits_equal(vel, g[f"vel{s}"]) and bits_equal(age, g[f"age{s}"]), f"step {s}"
+        assert np.array_equal(alive, g[f"alive{s}"])
+    org, d, b = unnormalised_rays(seed + 7, 1024)
+    assert bits_equal(o.hit(org, d, b), g["hits_unnormalised"])
+    if H.ref_pt_lib() is not None:     # authoring container: a second cloud straight against the reference build
+        ref = H.RefPT(scene, 8, 8, 8, True)
+        p2, v2, a2 = particle_cloud(seed + 1, 3000)
+        want = ref.particles_update(p2, v2, a2, 0.02, 0.05)
+        got = o.particles_update(p2, v2, a2, 0.02, 0.05, max_iter=0)
+        assert all(bits_equal(x, y) for x, y in zip(got[:3], want[:3])) and np.array_equal(got[3], want[3])
+
+
 def test_draw_ledger_cornell():
     """per Lambertian bounce 8 + 2 draws, 2 jitter draws per camera sample."""
     scene = pt_scene("cbox_lambertian")

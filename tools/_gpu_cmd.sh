@@ -1,3 +1,3 @@
 export TMPDIR=/tmp
-timeout -k 10 600 python3 bench.py --steps 8 --warmup 2 > gpurun_out/bench_r02_a.json 2> gpurun_out/bench_r02_a.err || tail -20 gpurun_out/bench_r02_a.err
-cat gpurun_out/bench_r02_a.json
+timeout -k 10 500 python3 -m pytest tests/test_pt_gpu.py -x -q -m gpu -k "particle or tonemap" > gpurun_out/t_part.log 2>&1 || { tail -40 gpurun_out/t_part.log; exit 1; }
+tail -2 gpurun_out/t_part.log
