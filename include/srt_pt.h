@@ -70,6 +70,30 @@ typedef struct srt_pt srt_pt; /* opaque */
 int srt_pt_create(int device, srt_pt** out);
 int srt_pt_destroy(srt_pt* pt);
 
+/* ---- one render over the GPUs of a node, inside one process ----------------------------------
+ * The reference's parallel axis is the epoch fan-out of Pathtracer::begin_render over its thread pool
+ * (rays/pathtracer.cpp:250-280); here an epoch is cut into 32 x 32 image tiles dealt round-robin to `n` devices.  A group
+ * owns one context per rank (rank r renders the tiles t with t % n == r; the scene is replicated: make every scene / camera /
+ * kernel call on each srt_pt_group_context(g, r), r = 0 .. n-1), one stream per rank, and the exchange buffers.
+ * srt_pt_group_render_epoch = every rank's srt_pt_render_epoch_device, ONE ncclGather of the tile radiance to rank 0 over
+ * RCCL / xGMI (no reduction: the tiles are disjoint), srt_pt_untile_device on rank 0; the image is bit-identical to a
+ * single context's.  RCCL is loaded at run time when n > 1 and every rank has its own device; ranks that share a device
+ * (how the path is exercised on a one-GPU box) gather with device-to-device copies (SRT_PT_GATHER=copy|rccl forces one).
+ * srt_pt_group_set_params replaces srt_pt_set_params for the members (it also sizes the exchange buffers).
+ * The device form leaves the width*height*3 float image (row 0 = bottom) on rank 0's device and returns the stream it is
+ * ordered on (srt_pt_accumulate_device / srt_pt_tonemap_device can follow on that stream); the host form copies it out.
+ * One process per GPU with an external collective (torch.distributed / RCCL) remains available through srt_pt_set_tiling. */
+typedef struct srt_pt_group srt_pt_group; /* opaque */
+int srt_pt_create_multi(const int* devices, int n, srt_pt_group** out);
+int srt_pt_group_destroy(srt_pt_group* g);
+int srt_pt_group_size(srt_pt_group* g);
+srt_pt* srt_pt_group_context(srt_pt_group* g, int rank);
+int srt_pt_group_uses_rccl(srt_pt_group* g);
+int srt_pt_group_set_params(srt_pt_group* g, uint32_t width, uint32_t height, uint32_t max_depth);
+int srt_pt_group_render_epoch(srt_pt_group* g, uint64_t seed, uint32_t sample_base, uint32_t samples, float* rgb_out);
+int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sample_base, uint32_t samples, float** d_image_out,
+                                     void** stream_out);
+
 /* ---- build_scene ---------------------------------------------------------------------------- */
 int srt_pt_scene_begin(srt_pt* pt);
 int srt_pt_add_material(srt_pt* pt, const srt_pt_material* m, uint32_t* index_out);

@@ -250,4 +250,4 @@ class SoftwareRenderer:
         _check(self._lib, self._lib.srt_raster_sync(self._ctx))
 
 
-from ._pt_bindings import Pathtracer, Scene  # noqa: E402,F401
+from ._pt_bindings import Pathtracer, PathtracerGroup, Scene  # noqa: E402,F401

@@ -20,6 +20,15 @@ COUNTER_NAMES = ("rays", "box_tests", "objects_entered", "tri_tests", "sphere_te
 
 def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.srt_pt_create_multi.argtypes = [c_void_p, c_int, POINTER(c_void_p)]
+    lib.srt_pt_group_destroy.argtypes = [c_void_p]
+    lib.srt_pt_group_size.argtypes = [c_void_p]
+    lib.srt_pt_group_context.argtypes = [c_void_p, c_int]
+    lib.srt_pt_group_context.restype = c_void_p
+    lib.srt_pt_group_uses_rccl.argtypes = [c_void_p]
+    lib.srt_pt_group_set_params.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32]
+    lib.srt_pt_group_render_epoch.argtypes = [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]
+    lib.srt_pt_group_render_epoch_device.argtypes = [c_void_p, c_uint64, c_uint32, c_uint32, POINTER(c_void_p), POINTER(c_void_p)]
     lib.srt_pt_destroy.argtypes = [c_void_p]
     lib.srt_pt_scene_begin.argtypes = [c_void_p]
     lib.srt_pt_add_material.argtypes = [c_void_p, POINTER(PtMaterial), POINTER(c_uint32)]
@@ -91,13 +100,17 @@ class Pathtracer:
     device = -1 creates a host-only context: scene assembly and BVH inspection work, rendering raises.
     """
 
-    def __init__(self, device: int = 0, n_threads: int | None = None):
+    def __init__(self, device: int = 0, n_threads: int | None = None, _borrowed_ctx=None):
         from . import SrtError, _check, load_library
 
         self._SrtError, self._check = SrtError, _check
         self._lib = load_library()
         self._ctx = c_void_p()
-        _check(self._lib, self._lib.srt_pt_create(device, ctypes.byref(self._ctx)))
+        self._borrowed = _borrowed_ctx is not None       # a member context of a PathtracerGroup: the group destroys it
+        if self._borrowed:
+            self._ctx = c_void_p(_borrowed_ctx)
+        else:
+            _check(self._lib, self._lib.srt_pt_create(device, ctypes.byref(self._ctx)))
         self.n_threads = n_threads or os.cpu_count() or 1
         self.out_w = self.out_h = 0
         self.n_samples = 0
@@ -111,7 +124,8 @@ class Pathtracer:
 
     def close(self) -> None:
         if self._ctx:
-            self._lib.srt_pt_destroy(self._ctx)
+            if not self._borrowed:
+                self._lib.srt_pt_destroy(self._ctx)
             self._ctx = c_void_p()
 
     def __del__(self):  # pragma: no cover
@@ -365,3 +379,66 @@ class Pathtracer:
 
     def sync(self) -> None:
         self._check(self._lib, self._lib.srt_pt_sync(self._ctx))
+
+
+class PathtracerGroup:
+    """srt_pt_create_multi: one render sharded by image tile over several devices inside one process (include/srt_pt.h).
+    members[r] is a Pathtracer over rank r's context (scene / camera / kernel calls are made on every member)."""
+
+    def __init__(self, devices):
+        from . import SrtError, _check, load_library
+
+        self._SrtError, self._check = SrtError, _check
+        self._lib = load_library()
+        self._g = c_void_p()
+        devs = (c_int * len(devices))(*[int(d) for d in devices])
+        _check(self._lib, self._lib.srt_pt_create_multi(devs, len(devices), ctypes.byref(self._g)))
+        self.members = [Pathtracer(_borrowed_ctx=self._lib.srt_pt_group_context(self._g, r)) for r in range(len(devices))]
+        self.out_w = self.out_h = 0
+
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.srt_pt_group_uses_rccl(self._g))
+
+    def set_params(self, w: int, h: int, pixel_samples: int, depth: int, use_bvh: bool) -> None:
+        for m in self.members:
+            m.out_w, m.out_h, m.n_samples, m.max_depth, m.scene_use_bvh = int(w), int(h), int(pixel_samples), int(depth), bool(use_bvh)
+        self.out_w, self.out_h = int(w), int(h)
+        self._check(self._lib, self._lib.srt_pt_group_set_params(self._g, int(w), int(h), int(depth)))
+
+    def build_scene(self, scene) -> None:
+        for m in self.members:
+            m.build_scene(scene)
+
+    def set_camera(self, camera) -> None:
+        for m in self.members:
+            m.set_camera(camera)
+
+    def set_kernel(self, mode: int) -> None:
+        for m in self.members:
+            m.set_kernel(mode)
+
+    def set_elision(self, on: bool) -> None:
+        for m in self.members:
+            m.set_elision(on)
+
+    def render_epoch(self, seed: int, sample_base: int, samples: int) -> np.ndarray:
+        out = np.zeros((self.out_h, self.out_w, 3), np.float32)
+        self._check(self._lib, self._lib.srt_pt_group_render_epoch(self._g, seed, sample_base, samples, _p(out)))
+        return out
+
+    def ray_count(self, reset: bool = False):
+        r = [m.ray_count(reset) for m in self.members]
+        return sum(x[0] for x in r), sum(x[1] for x in r)
+
+    def close(self) -> None:
+        if self._g:
+            for m in self.members:
+                m.close()
+            self._lib.srt_pt_group_destroy(self._g)
+            self._g = c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
