@@ -1,0 +1,34 @@
+// pt_dropin.cpp — proves the part of the drop-in PT::Pathtracer that touches the reference's Camera: the accessor of
+// soft-rendering-toolsets_amd/host/camera_iview.h returns exactly the private matrix Camera::generate_ray uses.
+//
+// TEST INFRASTRUCTURE ONLY.  Output: oracle/_ref/libdropin_pt.so (git-ignored), built from this file and the reference's own
+// util/camera.cpp where it lies.  This translation unit is compiled with -fno-access-control so that it can ALSO read
+// Camera::iview directly and compare; camera_iview.h itself needs no such flag (that is the point: the product's class reads
+// the matrix through an explicit template instantiation, without a patch to util/camera.h).
+#include <cstring>
+
+#include "rays/camera_iview.h"   // (the overlay of oracle/Makefile places the drop-in's files into src/rays/)
+#include "util/camera.h"
+
+extern "C" {
+
+// A camera driven like the GUI drives it: look_at(center, pos), then `nops` operations {kind, a, b}: 0 mouse_orbit(a, b),
+// 1 mouse_move(a, b), 2 mouse_radius(a).  Outputs (16 floats each, Mat4::data order): the accessor's matrix, the private member
+// read directly, and get_view().inverse() - what the drop-in would have to pass without the accessor.
+int dropin_camera_iview(const float pos[3], const float center[3], const float* ops, int nops, float accessor_out[16],
+                        float private_out[16], float view_inverse_out[16]) {
+  Camera c(Vec2(1280.0f, 720.0f));
+  c.look_at(Vec3(center[0], center[1], center[2]), Vec3(pos[0], pos[1], pos[2]));
+  for (int k = 0; k < nops; k++) {
+    const float* o = ops + 3 * k;
+    if (o[0] == 0.0f) c.mouse_orbit(Vec2(o[1], o[2]));
+    else if (o[0] == 1.0f) c.mouse_move(Vec2(o[1], o[2]));
+    else c.mouse_radius(o[1]);
+  }
+  const Mat4& a = srt_host::camera_iview(c);
+  const Mat4 vi = c.get_view().inverse();
+  for (int i = 0; i < 16; i++) { accessor_out[i] = a.data[i]; private_out[i] = c.iview.data[i]; view_inverse_out[i] = vi.data[i]; }
+  return 0;
+}
+
+}  // extern "C"

@@ -4,6 +4,8 @@
 
 #include <cstring>
 
+#include "camera_iview.h"
+
 #include "../gui/render.h"
 
 namespace PT {
@@ -29,35 +31,41 @@ srt_pt_material make_material(uint32_t type, Spectrum a, Spectrum b, float ior) 
 
 } // namespace
 
-Pathtracer::Pathtracer(Gui::Widget_Render& gui, Vec2) : gui(gui) {
-    check(srt_pt_create(0, &ctx), "srt_pt_create");
-    // The BSDF-sampled direct ray whose term the reference adds and subtracts again is not traced where that is provably
-    // result-neutral (srt_pt.h: srt_pt_set_elision); the image is bit-identical, renders of Cornell-type scenes ~25 % faster.
-    check(srt_pt_set_elision(ctx, 1), "srt_pt_set_elision");
+static void fatal(const char* what, int status, const char* message) {
+    die("%s failed (%d): %s", what, status, message);
+}
+
+Pathtracer::Pathtracer(Gui::Widget_Render& gui, Vec2) : gui(gui), core(nullptr, 0, fatal) {
 }
 
 Pathtracer::~Pathtracer() {
-    cancel();
-    srt_pt_destroy(ctx);
+    core.cancel();
 }
 
 void Pathtracer::set_samples(size_t samples) {
-    n_samples = samples;
+    core.set_samples(samples);
 }
 
 void Pathtracer::set_params(size_t w, size_t h, size_t samples, size_t depth, bool use_bvh) {
-    out_w = w;
-    out_h = h;
-    n_samples = samples;
-    max_depth = depth;
     scene_use_bvh = use_bvh;
-    accumulator.resize(out_w, out_h);
-    epoch_buf.assign(3 * out_w * out_h, 0.0f);
-    check(srt_pt_set_params(ctx, (uint32_t)w, (uint32_t)h, (uint32_t)depth), "srt_pt_set_params");
+    accumulator.resize(w, h);
+    core.set_params(w, h, samples, depth);
+}
+
+void Pathtracer::build_scene(Scene& layout_scene) {
+    for(int r = 0; r < core.ranks(); r++) feed_scene(core.context(r), layout_scene);   // replicated: a few MB per device
+    // the BVH<Object> boxes for visualize_bvh: fixed until the next build_scene
+    bvh_boxes.clear(); bvh_links.clear();
+    float none_f[6]; uint32_t none_u[4];
+    const long n = srt_pt_dump_bvh(core.context(0), -1, none_f, none_u, 0, nullptr);
+    if(n > 0) {
+        bvh_boxes.resize(6 * (size_t)n); bvh_links.resize(4 * (size_t)n);
+        srt_pt_dump_bvh(core.context(0), -1, bvh_boxes.data(), bvh_links.data(), (size_t)n, nullptr);
+    }
 }
 
 // The object walk of the reference's build_scene, feeding the C ABI instead of PT::Object constructors.
-void Pathtracer::build_scene(Scene& layout_scene) {
+void Pathtracer::feed_scene(srt_pt* ctx, Scene& layout_scene) {
     check(srt_pt_scene_begin(ctx), "srt_pt_scene_begin");
     bool warned = false;
     layout_scene.for_items([&, this](Scene_Item& item) {
@@ -183,116 +191,59 @@ void Pathtracer::build_scene(Scene& layout_scene) {
     check(srt_pt_scene_commit(ctx, scene_use_bvh ? 1 : 0), "srt_pt_scene_commit");
 }
 
-void Pathtracer::accumulate(const float* epoch) {
-    std::lock_guard<std::mutex> lock(accumulator_mut);
-    accumulator_samples++;
-    for(size_t j = 0; j < out_h; j++) {
-        for(size_t i = 0; i < out_w; i++) {
-            Spectrum& s = accumulator.at(i, j);
-            const float* e = epoch + 3 * (j * out_w + i);
-            const Spectrum n(e[0], e[1], e[2]);
-            s += (n - s) * (1.0f / accumulator_samples);
-        }
-    }
-}
-
-void Pathtracer::worker(size_t samples_per_epoch, size_t first_sample) {
-    for(size_t s = 0; s < n_samples; s += samples_per_epoch) {
-        if(cancel_flag.load()) return;
-        size_t samples = (s + samples_per_epoch) > n_samples ? n_samples - s : samples_per_epoch;
-        check(srt_pt_render_epoch(ctx, seed, (uint32_t)(first_sample + s), (uint32_t)samples, epoch_buf.data()),
-              "srt_pt_render_epoch");
-        accumulate(epoch_buf.data());
-        size_t completed = completed_epochs++;
-        if(completed + 1 == total_epochs)
-            render_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_render0).count();
-    }
-}
-
 void Pathtracer::begin_render(Scene& layout_scene, const Camera& cam, bool add_samples) {
-    size_t n_threads = std::thread::hardware_concurrency();
-    size_t samples_per_epoch = std::max(size_t(1), n_samples / (n_threads * 10));
-
-    cancel();
-    total_epochs = n_samples / samples_per_epoch + !!(n_samples % samples_per_epoch);
-
+    core.cancel();
     if(!add_samples) {
-        accumulator.clear({});
-        accumulator_samples = 0;
-        samples_done = 0;
-        t_build0 = std::chrono::steady_clock::now();
+        const auto t0 = std::chrono::steady_clock::now();
         build_scene(layout_scene);
-        build_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_build0).count();
+        core.note_build_time(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
     }
-    t_render0 = std::chrono::steady_clock::now();
-
+    // the matrix Camera::generate_ray itself uses (camera_iview.h): bit-identical camera rays, no header patch
     float iview[16];
-#ifdef SRT_CAMERA_HAS_IVIEW
-    mat_to_array(cam.get_iview(), iview);          // exact: the matrix Camera::generate_ray uses
-#else
-    mat_to_array(cam.get_view().inverse(), iview);  // util/camera.h has no iview getter; see INTEGRATION.md
-#endif
-    check(srt_pt_set_camera(ctx, iview, cam.get_fov(), cam.get_ar()), "srt_pt_set_camera");
-
-    const size_t first = samples_done;
-    samples_done += n_samples;
-    render_thread = std::thread([this, samples_per_epoch, first]() { worker(samples_per_epoch, first); });
+    mat_to_array(srt_host::camera_iview(cam), iview);
+    core.begin(iview, cam.get_fov(), cam.get_ar(), add_samples);
 }
 
 void Pathtracer::cancel() {
-    cancel_flag = true;
-    if(render_thread.joinable()) render_thread.join();
-    completed_epochs = 0;
-    total_epochs = 0;
-    cancel_flag = false;
+    core.cancel();
 }
 
 bool Pathtracer::in_progress() const {
-    return completed_epochs.load() < total_epochs;
+    return core.in_progress();
 }
 
 float Pathtracer::progress() const {
-    return (float)completed_epochs.load() / (float)total_epochs;
+    return core.progress();
 }
 
 std::pair<float, float> Pathtracer::completion_time() const {
-    return {(float)(build_ns.load() * 1e-9), (float)(render_ns.load() * 1e-9)};
+    return core.completion_time();
 }
 
 const HDR_Image& Pathtracer::get_output() {
+    core.copy_accumulator(accumulator_copy);
+    auto [w, h] = accumulator.dimension();
+    for(size_t i = 0; i < w * h && 3 * i + 2 < accumulator_copy.size(); i++)
+        accumulator.at(i) = Spectrum(accumulator_copy[3 * i], accumulator_copy[3 * i + 1], accumulator_copy[3 * i + 2]);
     return accumulator;
 }
 
 void Pathtracer::tonemap_to(std::vector<unsigned char>& data, float exposure) {
-    std::lock_guard<std::mutex> lock(accumulator_mut);
-    if(exposure > 0.0f) display_exposure = exposure;
-    auto [w, h] = accumulator.dimension();
-    if(data.size() != w * h * 4) data.resize(w * h * 4);
-    if(w == 0 || h == 0) return;
-    tonemap_in.resize(w * h * 3);
-    const HDR_Image& acc = accumulator;
-    for(size_t i = 0; i < w * h; i++) {
-        const Spectrum s = acc.at(i);
-        tonemap_in[3 * i] = s.r;
-        tonemap_in[3 * i + 1] = s.g;
-        tonemap_in[3 * i + 2] = s.b;
-    }
-    check(srt_pt_tonemap(ctx, tonemap_in.data(), (uint32_t)w, (uint32_t)h, display_exposure, data.data()), "srt_pt_tonemap");
+    core.tonemap(data, exposure);
 }
 
 const GL::Tex2D& Pathtracer::get_output_texture(float exposure) {
     tonemap_to(tonemap_out, exposure);
-    auto [w, h] = accumulator.dimension();
-    output_tex.image((int)w, (int)h, tonemap_out.data());
+    output_tex.image((int)core.width(), (int)core.height(), tonemap_out.data());
     return output_tex;
 }
 
 // Boxes of the BVH<Object> built for the GPU (same node arrays as the reference's, student/bvh.inl:324-372).
 size_t Pathtracer::visualize_bvh(GL::Lines& lines, GL::Lines& active, size_t level) {
-    std::vector<float> boxes(6 * 4096);
-    std::vector<uint32_t> links(4 * 4096);
-    long n = srt_pt_dump_bvh(ctx, -1, boxes.data(), links.data(), 4096, nullptr);
-    if(n <= 0) return 0;
+    const std::vector<float>& boxes = bvh_boxes;        // every node of the tree (build_scene sized them by the node count)
+    const std::vector<uint32_t>& links = bvh_links;
+    const size_t n = links.size() / 4;
+    if(n == 0) return 0;
     size_t max_level = 0;
     std::vector<std::pair<uint32_t, size_t>> stack{{0u, size_t(0)}};
     while(!stack.empty()) {
@@ -308,7 +259,7 @@ size_t Pathtracer::visualize_bvh(GL::Lines& lines, GL::Lines& active, size_t lev
         const int e[12][2] = {{0, 1}, {0, 2}, {0, 3}, {7, 5}, {7, 6}, {7, 4}, {2, 4}, {2, 5}, {3, 6}, {3, 5}, {1, 4}, {1, 6}};
         for(auto& ed : e) add.add(c[ed[0]], c[ed[1]], color);
         const uint32_t l = links[4 * idx + 2], r = links[4 * idx + 3];
-        if(l != r) {
+        if(l != r && l < n && r < n) {
             stack.push_back({l, lvl + 1});
             stack.push_back({r, lvl + 1});
         }

@@ -29,6 +29,7 @@
 #include "object.h"
 
 #include "srt_pt.h"
+#include "pathtracer_core.h"
 
 namespace Gui {
 class Widget_Render;
@@ -58,36 +59,26 @@ public:
     float progress() const;
     std::pair<float, float> completion_time() const;
 
-    // Not in the reference: RNG seed of the next render (the reference is unseeded) and the GPU to use.
-    void set_seed(unsigned long long s) { seed = s; }
+    // Not in the reference: RNG seed of the next render (the reference is unseeded).
+    void set_seed(unsigned long long s) { core.set_seed(s); }
 
 private:
-    void build_scene(Scene& scene);   // rays/pathtracer.cpp:66-176 -> srt_pt_scene_*
-    void accumulate(const float* epoch);  // rays/pathtracer.cpp:195-207
-    void worker(size_t samples_per_epoch, size_t first_sample);
+    void build_scene(Scene& scene);              // rays/pathtracer.cpp:66-176 -> srt_pt_scene_* on every device's context
+    void feed_scene(srt_pt* ctx, Scene& scene);  // the object / light / particle walk for one context
 
     Gui::Widget_Render& gui;
-    srt_pt* ctx = nullptr;
-    std::thread render_thread;
-    std::atomic<bool> cancel_flag{false};
+    // Everything that does not need Scene: contexts of every visible GPU (image tiles + one RCCL gather per epoch), the
+    // epoch scheme, the worker, the running mean, cancel / progress, the display epilogue (pathtracer_core.h).
+    srt_host::RenderCore core;
 
-    HDR_Image accumulator;
+    HDR_Image accumulator;           // what get_output() hands out: refreshed from the core's running mean
+    std::vector<float> accumulator_copy;
     GL::Tex2D output_tex;            // display texture fed by tonemap_to
-    float display_exposure = 1.0f;   // HDR_Image::exposure
-    std::vector<float> tonemap_in;
     std::vector<unsigned char> tonemap_out;
-    std::mutex accumulator_mut;
-    size_t total_epochs = 0, accumulator_samples = 0;
-    std::atomic<size_t> completed_epochs{0};
-    size_t samples_done = 0;   // sample index the next epoch starts at ("Add Samples" continues it)
-
-    std::chrono::steady_clock::time_point t_build0, t_render0;
-    std::atomic<long long> build_ns{0}, render_ns{0};
-
     bool scene_use_bvh = true;
-    size_t out_w = 0, out_h = 0, n_samples = 0, max_depth = 0;
-    unsigned long long seed = 0;
-    std::vector<float> epoch_buf;
+    // BVH<Object> node arrays of the last build_scene, kept for visualize_bvh (no context call while a render is in flight)
+    std::vector<float> bvh_boxes;
+    std::vector<uint32_t> bvh_links;
 };
 
 } // namespace PT

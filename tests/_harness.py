@@ -511,6 +511,32 @@ class EmuPT(_SceneFeeder):
         self.lib.emu_destroy(self.h_)
 
 
+_core_driver = None
+
+
+def pt_core_driver():
+    """C surface over srt_host::RenderCore (the Scene-independent part of the drop-in PT::Pathtracer), linked to the product
+    library: tests/host_emu/pt_core_driver.cpp + soft-rendering-toolsets_amd/host/pathtracer_core.cpp, built with g++."""
+    global _core_driver
+    if _core_driver is None:
+        out = os.path.join(ORACLE_DIR, "_build", "libpt_core_driver.so")
+        host = os.path.join(ROOT, "soft-rendering-toolsets_amd", "host")
+        lib = os.path.join(ROOT, "soft-rendering-toolsets_amd", "lib")
+        srcs = [os.path.join(ROOT, "tests", "host_emu", "pt_core_driver.cpp"), os.path.join(host, "pathtracer_core.cpp")]
+        deps = srcs + [os.path.join(host, "pathtracer_core.h"), os.path.join(ROOT, "include", "srt_pt.h")]
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+                            "-I/opt/rocm/include", *srcs, "-L" + lib, "-lsrt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                            "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", out], check=True)
+        _core_driver = ctypes.CDLL(out)
+        _core_driver.core_create.restype = ctypes.c_void_p
+        _core_driver.core_context.restype = ctypes.c_void_p
+        _core_driver.core_progress.restype = ctypes.c_float
+        _core_driver.core_epochs_accumulated.restype = ctypes.c_size_t
+    return _core_driver
+
+
 def oracle_tonemap(rgb, exposure):
     """HDR_Image::tonemap_to as restated by oracle/pt_oracle.c: (h, w, 3) float32 -> (h, w, 4) uint8."""
     rgb = np.ascontiguousarray(rgb, np.float32)

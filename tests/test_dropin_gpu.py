@@ -97,3 +97,80 @@ def test_group_gather_through_rccl(srt):
     for _ in range(2):
         assert np.array_equal(grp.render_epoch(1, 0, spp).view(np.uint32), want.view(np.uint32))
     grp.close()
+
+
+def _feed(srt, ctx_ptr, scene, w, h, depth):
+    m = srt.Pathtracer(_borrowed_ctx=ctx_ptr)
+    m.scene_use_bvh = True
+    m.build_scene(scene)
+    m.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_pathtracer_core_runs_the_reference_epoch_scheme(srt, devices):
+    """srt_host::RenderCore (host/pathtracer_core.cpp: what PT::Pathtracer is without the Scene walk) linked to the product
+    library and run: begin_render's epoch scheme with the asynchronous worker, the running mean of epoch means, "Add Samples",
+    cancel, progress, and the display epilogue - against the oracle's epochs folded by the oracle's accumulate."""
+    import time
+
+    D = H.pt_core_driver()
+    scene = pt_scene("cbox")
+    w, h, depth, n, threads = 40, 28, 8, 45, 2
+    devs = (ctypes.c_int * len(devices))(*devices)
+    core = ctypes.c_void_p(D.core_create(devs, len(devices)))
+    assert D.core_ranks(core) == len(devices)
+    D.core_set_threads(core, ctypes.c_size_t(threads))
+    D.core_set_params(core, ctypes.c_size_t(w), ctypes.c_size_t(h), ctypes.c_size_t(n), ctypes.c_size_t(depth))
+    for r in range(len(devices)):
+        _feed(srt, D.core_context(core, r), scene, w, h, depth)
+    cam = scene["camera"]
+    iview = np.ascontiguousarray(cam["iview"], np.float32)
+    D.core_set_seed(core, ctypes.c_ulonglong(11))
+    D.core_begin(core, H.P(iview), ctypes.c_float(cam["vfov"]), ctypes.c_float(cam["ar"]), 0)
+    seen = []
+    while D.core_in_progress(core):
+        seen.append(float(D.core_progress(core)))
+        time.sleep(0.001)
+    D.core_wait(core)
+    assert all(0.0 <= p <= 1.0 for p in seen)
+    spe = max(1, n // (threads * 10))                       # rays/pathtracer.cpp:252-253
+    o = H.OraclePT(scene, w, h, depth, True)
+    want = np.zeros((h, w, 3), np.float32)
+    k = 0
+    for s in range(0, n, spe):
+        k += 1
+        H.oracle_accumulate(want, o.epoch(11, s, min(spe, n - s)), k)
+    got = np.zeros((h, w, 3), np.float32)
+    D.core_copy_accumulator(core, H.P(got))
+    assert int(D.core_epochs_accumulated(core)) == k
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "running mean of the epochs differs from the oracle's"
+    # "Add Samples": keeps the accumulator, continues the sample index (rays/pathtracer.cpp:258-264)
+    D.core_set_samples(core, ctypes.c_size_t(7))
+    D.core_begin(core, H.P(iview), ctypes.c_float(cam["vfov"]), ctypes.c_float(cam["ar"]), 1)
+    D.core_wait(core)
+    spe2 = max(1, 7 // (threads * 10))
+    for s in range(0, 7, spe2):
+        k += 1
+        H.oracle_accumulate(want, o.epoch(11, n + s, min(spe2, 7 - s)), k)
+    D.core_copy_accumulator(core, H.P(got))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the display epilogue runs on its own context: HDR_Image::tonemap_to of the accumulator
+    rgba = np.zeros((h, w, 4), np.uint8)
+    D.core_tonemap(core, H.P(rgba), ctypes.c_float(1.3))
+    assert np.array_equal(rgba, H.oracle_tonemap(want, 1.3))
+    # cancel between epochs: the worker stops, nothing is in progress, and a fresh render starts from zero
+    D.core_set_samples(core, ctypes.c_size_t(4000))
+    D.core_begin(core, H.P(iview), ctypes.c_float(cam["vfov"]), ctypes.c_float(cam["ar"]), 0)
+    time.sleep(0.02)
+    D.core_tonemap(core, H.P(rgba), ctypes.c_float(0.0))          # the GUI thread displays while the worker renders
+    D.core_cancel(core)
+    assert not D.core_in_progress(core) and int(D.core_epochs_accumulated(core)) < 4000 // max(1, 4000 // (threads * 10)) + 1
+    D.core_set_samples(core, ctypes.c_size_t(3))
+    D.core_begin(core, H.P(iview), ctypes.c_float(cam["vfov"]), ctypes.c_float(cam["ar"]), 0)
+    D.core_wait(core)
+    want2 = np.zeros((h, w, 3), np.float32)
+    for j in range(3):
+        H.oracle_accumulate(want2, o.epoch(11, j, 1), j + 1)
+    D.core_copy_accumulator(core, H.P(got))
+    assert np.array_equal(got.view(np.uint32), want2.view(np.uint32))
+    D.core_destroy(core)
