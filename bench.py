@@ -161,6 +161,66 @@ def raster_bench(device, frames=30, warmup=3):
     cpu_s = time.perf_counter() - t
     ok = ok and bool(np.array_equal(r_rgba, out))
     ren.close()
+    # what binds the tile kernel: vector-instruction issue and LDS, from the committed SQ counter passes of the same kernel sources
+    import glob
+    prof, why_not = None, "no committed PMC pass for the rasterizer"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_raster.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("kernel_source_sha16") == kernel_source_sha():
+            prof, why_not = doc, None
+            prof["_file"] = os.path.relpath(path, ROOT)
+            break
+        why_not = f"{os.path.relpath(path, ROOT)} was taken on other kernel sources: counters not reported"
+    hbm = {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "SURVEY.md 8(d): 40 B x (primitive, tile) entries + 4 B x pixels; the 256 MiB supersample buffer never leaves the CUs, "
+                   "so this is tiny by design"}
+    roof = dict(hbm, traffic=None)
+    if prof:
+        t = prof["raster_tiles_per_frame"]
+        tiles_us = next((v["avg_us"] for k, v in prof["kernels"].items() if "raster_tiles<false" in k), None)
+        rate = t["SQ_INSTS_VALU"] / (tiles_us * 1e-6)
+        roof = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_GUIDE / 1e9, "unit": "G wave-instructions/s",
+                "frac": rate / VALU_PEAK_GUIDE, "frac_ubench_ceiling": rate / (SIMDS / (VALU_NS_UBENCH * 1e-9)), "traffic": None,
+                "kernel": "raster_tiles<false, 16>", "kernel_us_profiled": tiles_us,
+                "valu_lane_utilisation": (t.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * t["SQ_ACTIVE_INST_VALU"])) if t.get("SQ_ACTIVE_INST_VALU") else None,
+                "wave_cycles_waiting": t.get("SQ_WAIT_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
+                "wave_cycles_issuing": t.get("SQ_ACTIVE_INST_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
+                "lds_instructions_per_frame": t.get("SQ_INSTS_LDS"), "lds_bank_conflict_cycles_per_frame": t.get("SQ_LDS_BANK_CONFLICT"),
+                "lds_active_cycles_per_frame": t.get("SQ_LDS_IDX_ACTIVE"),
+                "kernels_us_profiled": {k: v["avg_us"] for k, v in prof["kernels"].items()},
+                "source": prof["_file"], "hbm": hbm}
+    elif why_not:
+        roof["counters"] = why_not
+    stress = None
+    sp = os.path.join(H.GOLDEN, "stress_degenerate2_1024_ss4.npz")
+    if os.path.exists(sp):     # SURVEY.md 8(d)'s stress variant: 1000 frame-sized translucent triangles, 5.86 G sample tests (22.7 s in the reference)
+        gs = np.load(sp)
+        sw, sh, ssr = (int(x) for x in gs["meta"])
+        r2 = srt_amd.SoftwareRenderer(device)
+        r2.set_render_target(None, sw, sh)
+        r2.set_sample_rate(ssr)
+        r2.clear_target()
+        r2.submit(gs["prims"])
+        o2 = r2.resolve()
+        st2 = r2.stats()
+        r2.resolve_device(stream)
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(5):
+            r2.resolve_device(stream)
+        a1.record()
+        torch.cuda.synchronize()
+        sms = a0.elapsed_time(a1) / 5
+        stress = {"workload": "DrawSVG hardcore/02_degenerate_square2.svg 1024x1024 supersample=4", "ms_per_frame": sms,
+                  "sample_tests": int(st2.sample_tests), "fragments": int(st2.fragments), "sample_tests_per_s": st2.sample_tests / (sms * 1e-3),
+                  "mfrags_per_s": st2.fragments / (sms * 1e-3) / 1e6, "bit_exact_vs_reference_golden": bool(np.array_equal(o2, gs["rgba"])),
+                  "reference_cpu_s": 22.7, "reference_cpu_source": "BASELINE.md section 2 (survey-time probe, 1 thread)"}
+        r2.close()
     return {
         "metric": "Mfrags/s triangle fill", "value": st.fragments / (ms * 1e-3) / 1e6, "unit": "Mfrags/s",
         "ms_per_frame": ms, "wall_ms_per_frame": wall * 1e3 / frames, "frames": frames,
@@ -169,9 +229,7 @@ def raster_bench(device, frames=30, warmup=3):
                    "fragments": int(st.fragments), "sample_tests": int(st.sample_tests), "bin_entries": int(st.bin_entries)},
         "sample_tests_per_s": st.sample_tests / (ms * 1e-3),
         "bit_exact_vs_reference_golden": ok, "dtype": "f64 edge functions / f32 blend",
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "note": "tile kernel is LDS/VALU bound: the 256 MiB supersample buffer never leaves the CUs"},
+        "roofline": roof, "list_bytes": int(st.list_bytes), "stress": stress,
         "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1,
                          "kind": "reference" if use_ref else "port",
                          "sample": (("oracle/_ref/libref_raster.so = the reference's SoftwareRendererImp (g++ -O2)" if use_ref

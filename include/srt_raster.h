@@ -75,6 +75,7 @@ typedef struct srt_raster_stats_t {
     uint64_t fragments;      /* covered, in-bounds fill_sample calls reached from rasterize_triangle */
     uint64_t point_samples;  /* in-bounds fill_sample calls reached from rasterize_point */
     uint64_t bin_entries;    /* (primitive, tile) pairs processed */
+    uint64_t list_bytes;     /* device memory held by the two levels of ordered bin lists for this stream / target */
 } srt_raster_stats_t;
 
 const char* srt_last_error(void);

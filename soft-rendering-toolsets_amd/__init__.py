@@ -55,6 +55,7 @@ class RasterStats(ctypes.Structure):
         ("fragments", c_uint64),
         ("point_samples", c_uint64),
         ("bin_entries", c_uint64),
+        ("list_bytes", c_uint64),
     ]
 
 

@@ -48,7 +48,9 @@ struct RasterParams {
   uint32_t nprims;
   uint32_t coarse_tiles;         // a coarse bin is coarse_tiles x coarse_tiles tiles
   uint32_t coarse_x, coarse_y;   // coarse grid
-  uint32_t list_stride;          // entries reserved per coarse bin (= nprims)
+  uint32_t super_bx, super_by;   // a super-bin is super_bx x super_by coarse bins (first binning level)
+  uint32_t super_x, super_y;     // super grid (<= 8 x 8)
+  uint32_t super_stride;         // entries reserved per super-bin (= nprims)
 };
 
 // Everything about one SRT_PRIM_IMAGE record that does not depend on the sample, prepared on the host at upload
@@ -140,37 +142,96 @@ __global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass 1b: ordered coarse binning.  One workgroup per coarse bin (coarse_tiles^2 tiles) walks the whole
-// stream in order, 256 bounding boxes per step, and appends the indices of the overlapping primitives to
-// the bin's list with a block-wide ORDERED compaction (ballot + prefix), so every list is sorted by stream
-// position and painter's order survives.  A tile then scans its bin's list instead of the whole stream.
+// Pass 1b: ordered binning in two levels.  A block walks a candidate list IN ORDER, 1024 bounding boxes per step, and
+// appends the indices of those that overlap its rectangle with a block-wide ORDERED compaction (ballot + prefix over the
+// waves), so every output list is sorted by stream position and painter's order survives.
+//   level 1: one block per SUPER-bin (<= 8 x 8 of them), candidates = the whole stream -> super lists
+//   level 2: one block per coarse bin (coarse_tiles^2 tiles), candidates = its super-bin's list -> the lists the tiles scan
+// Work is (super-bins x primitives) + (bins x their super list) instead of (bins x primitives); the bin lists are packed
+// back to back at offsets that follow from the super counts (bin b of super-bin s gets room for s's whole list), so their
+// storage follows the entries the frame really has instead of bins x primitives.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void raster_coarse_bin(RasterParams P, const int4* __restrict__ bbox,
-                                                         uint32_t* __restrict__ lists, uint32_t* __restrict__ counts) {
-  __shared__ uint32_t wave_cnt[4];
-  const uint32_t bin = blockIdx.x;
-  const int cx = (int)(bin % P.coarse_x), cy = (int)(bin / P.coarse_x);
-  const int span = (int)(P.coarse_tiles * P.tile_s), span_y = (int)(P.coarse_tiles * P.tile_sy);
-  const int x0 = cx * span, y0 = cy * span_y, x1 = x0 + span - 1, y1 = y0 + span_y - 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* out = lists + (size_t)bin * P.list_stride;
-  uint32_t total = 0;
-  for (uint32_t base = 0; base < P.nprims; base += 256) {
-    const uint32_t idx = base + threadIdx.x;
-    int4 bb = make_int4(1, 1, 0, 0);
-    if (idx < P.nprims) bb = bbox[idx];
-    const bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
-    const unsigned long long m = __ballot(ov);
-    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+__device__ __forceinline__ uint32_t bins_of_super(const RasterParams& P, uint32_t sb) {
+  const uint32_t sx = sb % P.super_x, sy = sb / P.super_x;
+  const uint32_t bw = min(P.super_bx, P.coarse_x - sx * P.super_bx), bh = min(P.super_by, P.coarse_y - sy * P.super_by);
+  return bw * bh;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const int4* __restrict__ bbox, const uint32_t* __restrict__ in_lists,
+                                                         const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_lists,
+                                                         uint32_t* __restrict__ out_counts, uint32_t* __restrict__ offs) {
+  __shared__ uint32_t s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int x0, y0, x1, y1;
+  const uint32_t* __restrict__ in = nullptr;
+  uint32_t ncand;
+  uint32_t* out;
+  if (LEVEL == 1) {
+    const uint32_t sb = blockIdx.x, sx = sb % P.super_x, sy = sb / P.super_x;
+    const int span = (int)(P.super_bx * P.coarse_tiles * P.tile_s), span_y = (int)(P.super_by * P.coarse_tiles * P.tile_sy);
+    x0 = (int)sx * span; y0 = (int)sy * span_y; x1 = x0 + span - 1; y1 = y0 + span_y - 1;
+    ncand = P.nprims;
+    out = out_lists + (size_t)sb * P.super_stride;
+  } else {
+    const uint32_t bin = blockIdx.x, cx = bin % P.coarse_x, cy = bin / P.coarse_x;
+    const int span = (int)(P.coarse_tiles * P.tile_s), span_y = (int)(P.coarse_tiles * P.tile_sy);
+    x0 = (int)cx * span; y0 = (int)cy * span_y; x1 = x0 + span - 1; y1 = y0 + span_y - 1;
+    const uint32_t sxi = cx / P.super_bx, syi = cy / P.super_by, sb = syi * P.super_x + sxi;
+    in = in_lists + (size_t)sb * P.super_stride;
+    ncand = in_counts[sb];
+    // where this bin's list starts: room for every earlier super-bin's bins, then this bin's rank inside its super-bin
+    if (threadIdx.x < 64) {
+      uint32_t part = 0;
+      for (uint32_t k = (uint32_t)lane; k < sb; k += 64u) part += in_counts[k] * bins_of_super(P, k);
+      for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_down((int)part, off);
+      if (lane == 0) {
+        const uint32_t bw = min(P.super_bx, P.coarse_x - sxi * P.super_bx);
+        const uint32_t local = (cy - syi * P.super_by) * bw + (cx - sxi * P.super_bx);
+        s_base = part + local * ncand;
+      }
+    }
     __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const uint32_t c = wave_cnt[w]; all += c; before += (w < wave) ? c : 0u; }
-    if (ov) out[total + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
-    total += all;
-    __syncthreads();
+    out = out_lists + s_base;
+    if (threadIdx.x == 0) offs[bin] = s_base;
   }
-  if (threadIdx.x == 0) counts[bin] = total;
+  // K candidates per thread and step (candidate j * blockDim + thread of the step: coalesced loads; a step's order is
+  // j-major, the block-wide prefix below follows it): the serial chain of a block - load, ballot, barrier, scatter - is what
+  // a frame waits for at level 1, where <= 64 blocks walk the whole stream: 8192 candidates per step instead of 1024
+  constexpr int K = (LEVEL == 1) ? 8 : 1;
+  __shared__ uint32_t wave_cnt_k[2][K][16];
+  uint32_t total = 0;
+  int flip = 0;
+  for (uint32_t base = 0; base < ncand; base += blockDim.x * K, flip ^= 1) {
+    uint32_t idx[K];
+    bool ov[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const uint32_t k = base + (uint32_t)j * blockDim.x + threadIdx.x;
+      idx[j] = 0;
+      int4 bb = make_int4(1, 1, 0, 0);
+      if (k < ncand) { idx[j] = (LEVEL == 1) ? k : in[k]; bb = bbox[idx[j]]; }
+      ov[j] = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+    }
+    uint32_t lane_before[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      const unsigned long long m = __ballot(ov[j]);
+      lane_before[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt_k[flip][j][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();                                   // (the counts of the next step go to the other buffer: one barrier per step)
+    uint32_t at = total;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      uint32_t before = 0, all = 0;
+      for (int w = 0; w < nwaves; w++) { const uint32_t c = wave_cnt_k[flip][j][w]; all += c; before += (w < wave) ? c : 0u; }
+      if (ov[j]) out[at + before + lane_before[j]] = idx[j];
+      at += all;
+    }
+    total = at;
+  }
+  if (threadIdx.x == 0) out_counts[blockIdx.x] = total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,6 +291,7 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
                                                      const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ offs,
                                                      const ImageAux* __restrict__ aux, const float* __restrict__ tabs,
                                                      const uint8_t* __restrict__ texels,
                                                      uint32_t* __restrict__ rgba_out,
@@ -260,7 +322,7 @@ __global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_p
 
   // this tile's coarse bin: an ordered list of primitive indices
   const uint32_t bin = (uint32_t)(ty / (int)P.coarse_tiles) * P.coarse_x + (uint32_t)(tx / (int)P.coarse_tiles);
-  const uint32_t* __restrict__ list = lists + (size_t)bin * P.list_stride;
+  const uint32_t* __restrict__ list = lists + offs[bin];
   const uint32_t n = counts[bin];
   // software prefetch: the next 64 (index, bbox) pairs are in flight while the current ones are rasterized
   uint32_t nidx = 0;
@@ -447,8 +509,11 @@ struct srt_raster {
   srt_prim* d_prims = nullptr;
   int4* d_bbox = nullptr;
   size_t d_cap = 0;
-  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists (coarse bins x list_stride)
-  uint32_t* d_counts = nullptr; size_t counts_cap = 0;
+  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists, packed (raster_bin_pass<2>)
+  uint32_t* d_counts = nullptr; size_t counts_cap = 0; // per coarse bin: entries, then (second half) list offsets
+  uint32_t* d_super = nullptr; size_t super_cap = 0;   // super-bin lists (<= 64 x nprims) followed by their 64 counts
+  bool bins_dirty = true;                              // stream or target changed: the list storage has to be re-sized
+  size_t list_entries = 0;                             // room the packed bin lists need for the current stream / target
   uint32_t* d_rgba = nullptr;
   float4* d_samples = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -581,46 +646,76 @@ int upload_stream(srt_raster* r) {
   }
   r->P.nprims = (uint32_t)n;
   r->dirty = false;
+  r->bins_dirty = true;                          // another stream: the packed bin lists are sized on its first frame
   return SRT_OK;
 }
 
 // Enqueue setup + tile kernels for the current stream on `s`.
 int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   RasterParams& P = r->P;
-  // coarse grid: bins of c x c tiles, c chosen so that the list storage (bins * nprims entries) stays <= 64 Mi entries
-  {
-    uint32_t c = 4;
-    auto bins_for = [&](uint32_t cc) { return (uint64_t)((P.tiles_x + cc - 1) / cc) * ((P.tiles_y + cc - 1) / cc); };
-    while (bins_for(c) * (uint64_t)(P.nprims ? P.nprims : 1) > (64ull << 20) && c < 65536) c *= 2;
-    P.coarse_tiles = c;
-    P.coarse_x = (P.tiles_x + c - 1) / c;
-    P.coarse_y = (P.tiles_y + c - 1) / c;
-    P.list_stride = P.nprims ? P.nprims : 1;
-    const size_t nb = (size_t)P.coarse_x * P.coarse_y;
-    if (r->counts_cap < nb) {
-      if (r->d_counts) SRT_HIP(hipFree(r->d_counts));
-      r->d_counts = nullptr; r->counts_cap = 0;      // a failed allocation below must not leave a capacity behind
-      SRT_HIP(hipMalloc(&r->d_counts, nb * sizeof(uint32_t)));
-      r->counts_cap = nb;
-    }
-    if (r->lists_cap < nb * P.list_stride) {
-      if (r->d_lists) SRT_HIP(hipFree(r->d_lists));
-      r->d_lists = nullptr; r->lists_cap = 0;      // a failed allocation below must not leave a capacity behind
-      SRT_HIP(hipMalloc(&r->d_lists, nb * P.list_stride * sizeof(uint32_t)));
-      r->lists_cap = nb * P.list_stride;
-    }
-  }
   if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (P.nprims) {
     const int bs = 256;
     raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_aux, r->d_bbox,
                                                                       stats ? r->d_stats : nullptr);
   }
-  raster_coarse_bin<<<dim3(P.coarse_x * P.coarse_y), dim3(256), 0, s>>>(P, r->d_bbox, r->d_lists, r->d_counts);
+  // Ordered binning (raster_bin_pass): coarse bins of c x c tiles under <= 8 x 8 super-bins.  The first frame of a stream
+  // reads the 64 super counts back once to size the packed lists by the entries the frame really has; later frames of the
+  // same stream and target only enqueue.
+  for (uint32_t c = 4;; c *= 2) {
+    P.coarse_tiles = c;
+    P.coarse_x = (P.tiles_x + c - 1) / c;
+    P.coarse_y = (P.tiles_y + c - 1) / c;
+    if ((uint64_t)P.coarse_x * P.coarse_y > 8192 && c < 65536) continue;          // (keeps the bin count bounded on huge targets)
+    P.super_bx = (P.coarse_x + 7) / 8; P.super_by = (P.coarse_y + 7) / 8;
+    P.super_x = (P.coarse_x + P.super_bx - 1) / P.super_bx; P.super_y = (P.coarse_y + P.super_by - 1) / P.super_by;
+    P.super_stride = P.nprims ? P.nprims : 1;
+    const size_t nb = (size_t)P.coarse_x * P.coarse_y, ns = (size_t)P.super_x * P.super_y;
+    if (r->counts_cap < 2 * nb) {
+      if (r->d_counts) SRT_HIP(hipFree(r->d_counts));
+      r->d_counts = nullptr; r->counts_cap = 0;      // a failed allocation below must not leave a capacity behind
+      SRT_HIP(hipMalloc(&r->d_counts, 2 * nb * sizeof(uint32_t)));
+      r->counts_cap = 2 * nb;
+      r->bins_dirty = true;
+    }
+    if (r->super_cap < ns * P.super_stride + 64) {
+      if (r->d_super) SRT_HIP(hipFree(r->d_super));
+      r->d_super = nullptr; r->super_cap = 0;
+      SRT_HIP(hipMalloc(&r->d_super, (ns * P.super_stride + 64) * sizeof(uint32_t)));
+      r->super_cap = ns * P.super_stride + 64;
+      r->bins_dirty = true;
+    }
+    uint32_t* d_super_counts = r->d_super + ns * P.super_stride;
+    raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr);
+    if (r->bins_dirty) {
+      uint32_t h_counts[64];
+      SRT_HIP(hipMemcpyAsync(h_counts, d_super_counts, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      SRT_HIP(hipStreamSynchronize(s));
+      uint64_t need = 0;
+      for (uint32_t k = 0; k < ns; k++) {
+        const uint32_t sx = k % P.super_x, sy = k / P.super_x;
+        const uint64_t bw = std::min<uint32_t>(P.super_bx, P.coarse_x - sx * P.super_bx), bh = std::min<uint32_t>(P.super_by, P.coarse_y - sy * P.super_by);
+        need += (uint64_t)h_counts[k] * bw * bh;
+      }
+      if (need > (256ull << 20) && c < 65536) continue;                           // more than 1 GiB of lists: coarser bins
+      if (need >= (1ull << 32)) return srt::fail(SRT_ERR_UNSUPPORTED, "the frame's bin lists need %llu entries", (unsigned long long)need);
+      if (r->lists_cap < need + 1) {
+        if (r->d_lists) SRT_HIP(hipFree(r->d_lists));
+        r->d_lists = nullptr; r->lists_cap = 0;      // a failed allocation below must not leave a capacity behind
+        SRT_HIP(hipMalloc(&r->d_lists, (need + 1) * sizeof(uint32_t)));
+        r->lists_cap = need + 1;
+      }
+      r->list_entries = need;
+      r->bins_dirty = false;
+    }
+    raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, r->d_lists, r->d_counts, r->d_counts + nb);
+    break;
+  }
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
 #define SRT_TILES(STATS_, TSY_, ST_)                                                                                       \
-  raster_tiles<STATS_, TSY_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts, r->d_aux, \
+  raster_tiles<STATS_, TSY_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts,             \
+                                                                 r->d_counts + (size_t)P.coarse_x * P.coarse_y, r->d_aux,       \
                                                                  r->d_tabs, r->d_texels, r->d_rgba, so, ST_)
   const int tsy = P.tile_sy > 16 ? 32 : (P.tile_sy > 8 ? 16 : 8);
   if (stats) { if (tsy == 32) SRT_TILES(true, 32, r->d_stats); else if (tsy == 16) SRT_TILES(true, 16, r->d_stats); else SRT_TILES(true, 8, r->d_stats); }
@@ -668,6 +763,7 @@ int srt_raster_destroy(srt_raster* r) {
   (void)hipFree(r->d_prims);
   (void)hipFree(r->d_bbox);
   (void)hipFree(r->d_lists);
+  (void)hipFree(r->d_super);
   (void)hipFree(r->d_counts);
   (void)hipFree(r->d_rgba);
   (void)hipFree(r->d_samples);
@@ -744,6 +840,7 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   if (r->d_samples) { SRT_HIP(hipFree(r->d_samples)); r->d_samples = nullptr; }
   r->have_target = true;
   r->resolved = false;
+  r->bins_dirty = true;                          // another tiling: the packed bin lists are re-sized on the next frame
   return SRT_OK;
 }
 
@@ -826,6 +923,7 @@ int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out) {
   out->fragments = h[ST_FRAGMENTS];
   out->point_samples = h[ST_POINT_SAMPLES];
   out->bin_entries = h[ST_BIN_ENTRIES];
+  out->list_bytes = (uint64_t)(r->super_cap + r->lists_cap + r->counts_cap) * sizeof(uint32_t);
   return SRT_OK;
 }
 

@@ -38,6 +38,7 @@ SVG_CASES = [
     ("prism_alpha_400x300_ss2", "alpha/01_prism.svg", 400, 300, 2),
     ("buckyball_alpha_256_ss4", "alpha/03_buckyball.svg", 256, 256, 4),
     ("degenerate1_256_ss2", "hardcore/01_degenerate_square1.svg", 256, 256, 2),
+    ("degenerate2_512_ss2", "hardcore/02_degenerate_square2.svg", 512, 512, 2),   # 1000 frame-sized triangles (the stress SVG, reduced)
     ("lion_384_ss3", "illustration/05_lion.svg", 384, 384, 3),
     ("hexes_320x240_ss1", "illustration/02_hexes.svg", 320, 240, 1),
     # <image> elements: rasterize_image + Sampler2DImp::sample_trilinear over the reference's own mip chains
@@ -51,7 +52,25 @@ def main():
     ref = H.ref_raster()
     assert ref is not None, "build oracle/_ref first: make -C oracle ref"
     only_images = "--images-only" in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--stress" in sys.argv:
+        # SURVEY.md 8(d)'s stress variant at full size: hardcore/02_degenerate_square2.svg, 1024 x 1024, supersample 4 - 1000
+        # triangles, 5.86 G sample tests, 22 s in the reference.  Kept out of the raster_*.npz set (the CPU suite would spend a
+        # minute in the oracle on it); the GPU test and bench.py's stress line use it.
+        svg, w, h, sr = "hardcore/02_degenerate_square2.svg", 1024, 1024, 4
+        path = os.path.join(SVG_DIR, svg).encode()
+        rgba = np.zeros((h, w, 4), np.uint8)
+        ss = np.zeros((h * sr, w * sr, 4), np.float32)
+        assert ref.ref_raster_render_svg(path, w, h, sr, H.P(rgba), H.P(ss)) == 0
+        prims = np.zeros(100000, H.PRIM_DTYPE)
+        n = ref.ref_raster_svg_stream(path, w, h, sr, H.P(prims), ctypes.c_size_t(len(prims)))
+        np.savez_compressed(os.path.join(HERE, "stress_degenerate2_1024_ss4.npz"), prims=prims[:n].copy(), rgba=rgba,
+                            ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64), source=np.array(svg))
+        print(f"stress: {n} prims rgba sha {H.sha(rgba)[:12]}")
+        return
     for name, svg, w, h, sr in ([] if only_images else SVG_CASES):
+        if only and name not in only:
+            continue
         path = os.path.join(SVG_DIR, svg).encode()
         rgba = np.zeros((h, w, 4), np.uint8)
         ss = np.zeros((h * sr, w * sr, 4), np.float32)
@@ -71,7 +90,7 @@ def main():
         )
         print(f"{name}: {n} prims ({int((prims['kind'] == 1).sum())} triangles) rgba sha {H.sha(rgba)[:12]}")
 
-    for sr in (() if only_images else (1, 2, 3, 4, 5)):
+    for sr in (() if (only_images or only) else (1, 2, 3, 4, 5)):
         w, h = 97, 61
         prims = adversarial_stream(seed=1234 + sr, w=w, h=h)
         rgba, ss = H.ref_raster_prims(prims, w, h, sr, want_samples=True)
@@ -84,7 +103,7 @@ def main():
 
     # synthetic image streams: textures with the reference's mip chains, images folded over column / row 0,
     # minified below the last level, magnified, drawn under and over translucent triangles
-    for sr in (1, 2, 4):
+    for sr in (() if only else (1, 2, 4)):
         w, h = 90, 70
         prims, level0 = image_stream(seed=77 + sr, w=w, h=h)
         # Mip chains from the oracle's generate_mips, not the reference's: Sampler2DImp::generate_mips (texture.cpp:53-121)

@@ -135,6 +135,19 @@ def test_many_small_triangles_and_big_target(srt):
     o_rgba, _, c = H.oracle_raster_frame(prims, w, h, sr)
     assert np.array_equal(rgba, o_rgba)
     assert (st.sample_tests, st.fragments) == (int(c[0]), int(c[2]))
+    assert st.list_bytes < 100 << 20, "the two levels of bin lists are sized by the frame's entries, not bins x primitives"
+
+
+def test_stress_svg_at_full_size_matches_reference(srt):
+    """SURVEY.md 8(d)'s stress variant: hardcore/02_degenerate_square2.svg, 1024 x 1024, supersample 4 - 1000 frame-sized
+    translucent triangles, 5.86 G sample tests, every coarse bin lists every primitive.  RGBA8 and the float sample buffer
+    against the reference's (22 s there)."""
+    g = np.load(os.path.join(H.GOLDEN, "stress_degenerate2_1024_ss4.npz"))
+    w, h, sr = (int(x) for x in g["meta"])
+    rgba, ss, st = render(srt, g["prims"], w, h, sr, samples=True)
+    assert np.array_equal(rgba, g["rgba"])
+    assert H.sha(ss) == str(g["ss_sha256"])
+    assert st.sample_tests == 5858050128
 
 
 def test_points_only_stream(srt):

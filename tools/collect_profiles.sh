@@ -10,6 +10,16 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
+if [ "$scene" = raster ]; then
+  # the rasterizer on BASELINE configs[1]: kernel trace + two SQ counter passes over tools/raster_bench.py
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 100 > "$out/stats.log" 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$out/a" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 20 > "$out/a.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU --output-format csv -d "$out/b" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 20 > "$out/b.log" 2>&1
+  cd "$root"
+  python3 tools/make_raster_profile.py "$out" "$tag"
+  exit 0
+fi
 common="--scene $scene --no-cpu-baseline --no-cfg5 --no-overlap"
 cd /tmp
 if [ "$scene" = cbox ]; then statsopt="--steps 8 --warmup 1"; else statsopt="--steps 2 --warmup 1 --no-raster --no-elision"; fi

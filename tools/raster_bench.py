@@ -1,7 +1,32 @@
 #!/usr/bin/env python3
-"""Diagnostic: rasterizer frame time on the cfg2 stream (and a synthetic many-small-triangles stream)."""
-import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-r = bench.raster_bench(0, frames=50, warmup=5)
-print(json.dumps({k: r[k] for k in ("value", "ms_per_frame", "sample_tests_per_s", "bit_exact_vs_reference_golden")}))
+"""Diagnostic: frames of a golden raster stream in a loop (for rocprofv3 kernel stats / PMC passes).
+usage: raster_bench.py [golden npz] [frames]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import srt_amd
+
+name = sys.argv[1] if len(sys.argv) > 1 else "raster_cfg2_test3_1024_ss4.npz"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+g = np.load(os.path.join(ROOT, "tests", "golden", name))
+w, h, sr = (int(x) for x in g["meta"])
+ren = srt_amd.SoftwareRenderer(0)
+ren.set_render_target(None, w, h)
+ren.set_sample_rate(sr)
+ren.clear_target()
+ren.submit(g["prims"])
+out = ren.resolve()
+print("matches golden:", bool(np.array_equal(out, g["rgba"])))
+st = ren.stats()
+stream = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    ren.resolve_device(stream)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(frames):
+    ren.resolve_device(stream)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / frames
+print(f"{name}: {dt*1e3:.3f} ms/frame, {st.fragments/dt/1e6:.0f} Mfrags/s, {st.sample_tests/dt/1e9:.1f} G tests/s, bin entries {st.bin_entries}, list bytes {st.list_bytes}")
