@@ -4,7 +4,7 @@
 // builds as Mat4::translate(position) * rot.to_mat() (util/camera.cpp:141); `rot` and `iview` have no getter, and the public
 // get_view().inverse() differs from iview in the last bits (it is the inverse of an inverse).  An explicit template
 // instantiation may name a private member - access checking does not apply to explicit instantiations ([temp.spec]) - so
-// the cached matrix itself can be read: same bits, no patch.  oracle/ref_harness/pt_dropin.cpp proves it against the
+// the cached matrix itself can be read: same bits, no patch.  tests/test_dropin_cpu.py proves it against the
 // reference's Camera after look_at / orbit / move / zoom sequences.
 #pragma once
 

@@ -1,14 +1,10 @@
 export TMPDIR=/tmp
-timeout -k 10 600 python3 -m pytest tests/test_raster_gpu.py -x -q -m gpu > gpurun_out/t_raster.log 2>&1 || { tail -40 gpurun_out/t_raster.log; exit 1; }
-tail -2 gpurun_out/t_raster.log
-python3 tools/raster_bench.py raster_cfg2_test3_1024_ss4.npz 100
-python3 tools/raster_bench.py stress_degenerate2_1024_ss4.npz 10
-root=$(pwd); cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_raster -- python3 $root/tools/raster_bench.py raster_cfg2_test3_1024_ss4.npz 100 > $root/gpurun_out/prof_raster.log 2>&1
-cd $root
-f=$(ls gpurun_out/prof_raster/*/*kernel_stats.csv | head -1)
-python3 - <<PY
-import csv
-for r in csv.DictReader(open("$f")):
-    print(r["Name"][:70], r["Calls"], round(float(r["TotalDurationNs"])/1e6,3), "ms avg", round(float(r["AverageNs"])/1e3,2),"us")
-PY
+timeout -k 10 500 python3 -m pytest tests/test_pt_gpu.py -x -q -m gpu > gpurun_out/t_chain.log 2>&1 || { tail -40 gpurun_out/t_chain.log; exit 1; }
+tail -2 gpurun_out/t_chain.log
+SRT_CAST_STATS=1 python3 tools/pt_scene_bench.py blob7 1024 16 7 2>&1 | grep -E "cast (outer|fetch|interior_l|leaf_l|object_l)|mode"
+python3 tools/pt_scene_bench.py blob7 1024 64 7 2>&1 | grep -E "mode"
+SRT_NO_CHAIN=1 python3 tools/pt_scene_bench.py blob7 1024 64 7 2>&1 | grep -E "mode"
+timeout -k 10 600 python3 bench.py --steps 4 --warmup 1 --no-raster --no-cpu-baseline --no-elision 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('headline', d['value'], d['ms_per_step']); c=d['cfg5']; print('cfg5', c['value'], c['ms_per_step'], c['roofline']['stream_kernels_ms'])"
