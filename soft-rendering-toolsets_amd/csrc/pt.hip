@@ -471,7 +471,10 @@ int wave_trav(const srt_pt* pt) {
   if (m == 2) return sweeps_fit ? (blas ? 1 : 0) : -1;
   if (m == 3) return (sweeps_fit && !lights) ? (blas ? 1 : 0) : -1;
   if (m == 5) return (flat_fits && !lights) ? 2 : -1;
-  const bool sweeps_stream = sweeps_fit && blas && F.lazy_objects.size() <= kMaxLazy && stream_fits(F);
+  bool single_leaves = true;          // (the reference builds BVH<Object> leaves of one object; the streamed sweeps rely on it)
+  for (const WaveInterior& w : F.wave_tlas)
+    if ((w.l_ref < 0 && w.l_cnt > 1u) || (w.r_ref < 0 && w.r_cnt > 1u)) single_leaves = false;
+  const bool sweeps_stream = sweeps_fit && blas && single_leaves && F.lazy_objects.size() <= kMaxLazy && stream_fits(F);
   if (m == 6) return stream_fits(F) ? 3 : -1;
   if (m == 7) return sweeps_stream ? 4 : -1;
   // auto: a few objects, some of them meshes with a real BVH<Triangle> (BASELINE configs[4]): the sweeps stay, the walks of

@@ -349,6 +349,68 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
 }
 
 
+// TRAV 4 (the streamed sweeps): Object::hit of a mesh with a real BVH<Triangle> for the rays of a batch that need it.  Only the
+// ray -> object space step (Ray::transform, as object_testN does it) happens here; the walk itself is queued: the probe pass
+// (emit) writes the object-space rays to their fixed queue positions and flags them in emit_mask, the ray-cast kernel walks
+// them between two generations, the complete pass reads {hit, world distance, triangle} back.
+template <int NR>
+SRT_DEV void object_queueN(const DScene& S, uint32_t k, V3 org, const V3* d, const float* rb0, const float* rb1, bool* hit, float* dist,
+                           uint32_t* tri, const bool* need, const WaveParams& QP, uint32_t lane_global, bool emit, uint32_t& emit_mask) {
+  const Object& o = S.objects[k];
+  const uint32_t m = o.use_bvh >> 8;                     // ordinal of this mesh (pt_scene.h)
+#pragma unroll
+  for (int r = 0; r < NR; r++) { hit[r] = false; dist[r] = 0.0f; tri[r] = 0u; }
+  if (!emit) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (need[r]) {
+        const uint2 hv = QP.hits[(size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global];
+        hit[r] = hv.y != 0xFFFFFFFFu;
+        dist[r] = hit[r] ? __uint_as_float(hv.x) : 0.0f;
+        tri[r] = hit[r] ? hv.y : 0u;
+      }
+    }
+    return;
+  }
+  bool any = false;
+#pragma unroll
+  for (int r = 0; r < NR; r++) any = any || need[r];
+  if (__ballot(any) == 0ull) return;
+  V3 oorg = org;
+  V3 od[NR];
+  float ob0[NR], ob1[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) { od[r] = d[r]; ob0[r] = rb0[r]; ob1[r] = rb1[r]; }
+  if (o.has_trans != 0) {                                 // Ray::transform with the shared origin (as in object_testN)
+    oorg = mat_point_uniform(o.itrans, org);
+    float n2[NR], dn[NR], num[NR][3], q[NR][3];
+    bool nz[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      const V3 rd = mat_rotate(o.itrans, d[r]);
+      num[r][0] = rd.x; num[r][1] = rd.y; num[r][2] = rd.z;
+      n2[r] = norm2(rd);
+      nz[r] = false;
+    }
+    sqrtN<NR>(n2, nz, dn);
+    divNx3<NR, false>(num, dn, q);
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      ob0[r] *= dn[r]; ob1[r] *= dn[r];
+      od[r] = v3(q[r][0], q[r][1], q[r][2]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    if (need[r]) {
+      const size_t pos = (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global;
+      QP.ray_o[pos] = make_float4(oorg.x, oorg.y, oorg.z, ob0[r]);
+      QP.ray_d[pos] = make_float4(od[r].x, od[r].y, od[r].z, ob1[r]);
+      emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
+    }
+  }
+}
+
 // Scene arrays are passed as separate `const T* __restrict__` kernel arguments (not inside DScene): only then can
 // the compiler prove that the stores to records / sample_out do not clobber them and turn the wave-uniform
 // scene reads into scalar loads (s_load_*), which is what keeps the sweeps off the vector memory path.
@@ -777,7 +839,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             const uint32_t first = (uint32_t)~ref;
             for (uint32_t k = first; k < first + n; k++) {
               bool h[NR]; float dd[NR]; uint32_t tt[NR];
-              object_testN<LAZY, NR, TRAV == 4>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, need, cidx, &P, lane_global, pass == 1, &emit_mask);
+              // (TRAV 4: a mesh with a real BVH<Triangle> is a leaf of its own - checked on the host - and goes through `queued`)
+              object_testN<TRAV == 1, NR>(S, k, org, d, rb0, rb1, cnt, h, dd, tt, need, cidx);
 #pragma unroll
               for (int r = 0; r < NR; r++) fold(out[r], h[r], dd[r], k, tt[r]);
             }
@@ -796,6 +859,28 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if constexpr (!LAZY) {                           // no per-lane walks: both children straight, in order
           eval_child(W.l_ref, W.l_cnt, L, act);
           eval_child(W.r_ref, W.r_cnt, R, act);
+        } else if constexpr (TRAV == 4) {
+          // The streamed sweeps: every other child exactly as above (the very code of the Cornell kernel); a leaf that holds a
+          // mesh with a real BVH<Triangle> comes after its sibling and costs a ray -> object space step and a queue access.
+          // The walks are queued in the probe pass, when no mesh result exists yet, and read back in the complete pass: the
+          // set of rays that "need" a mesh must not depend on any mesh's result, so a sibling whose subtree holds such a mesh
+          // counts as unknown (a superset again; what is not needed is never selected).
+          const uint32_t lz = S.wave_lazy[q];
+          const bool lazy_l = lazy_leaf(W.l_ref, W.l_cnt), lazy_r = lazy_leaf(W.r_ref, W.r_cnt);
+          auto queued = [&](int32_t ref, bool is_left, const Hit* other, bool other_known, Hit* out) {
+            bool need[NR], h[NR]; float dd[NR]; uint32_t tt[NR];
+            need_of(is_left, other, other_known, need);
+            const uint32_t k = (uint32_t)~ref;
+            object_queueN<NR>(S, k, org, d, rb0, rb1, h, dd, tt, need, P, lane_global, pass == 1, emit_mask);
+#pragma unroll
+            for (int r = 0; r < NR; r++) { out[r] = no_hit(); fold(out[r], h[r], dd[r], k, tt[r]); }
+          };
+#pragma unroll
+          for (int r = 0; r < NR; r++) { L[r] = no_hit(); R[r] = no_hit(); }
+          if (!lazy_l) eval_child(W.l_ref, W.l_cnt, L, act);
+          if (!lazy_r) eval_child(W.r_ref, W.r_cnt, R, act);
+          if (lazy_l) queued(W.l_ref, true, R, (lz & 2u) == 0u, L);
+          if (lazy_r) queued(W.r_ref, false, L, (lz & 1u) == 0u, R);
         } else {
         const bool lazy_l = lazy_leaf(W.l_ref, W.l_cnt), lazy_r = lazy_leaf(W.r_ref, W.r_cnt);
         // TRAV 4: the walks are queued in the probe pass, when no mesh result exists yet, and read back in the complete pass:
