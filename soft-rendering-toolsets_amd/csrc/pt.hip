@@ -332,9 +332,11 @@ struct srt_pt {
     uint2* d_hits = nullptr; size_t hits_n = 0;
     StreamCounters* d_sc = nullptr;
     unsigned long long* d_block_counters = nullptr; size_t block_counters_n = 0;
+    uint32_t* d_cast_spill = nullptr; size_t cast_spill_words = 0;   // the ray-cast kernel's traversal frames beyond those in LDS
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
+  uint32_t cast_lds_frames = 0;                                 // traversal frames per lane kept in LDS (the deeper ones: d_cast_spill)
   int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0; uint32_t cast_depth = 0;   // pt_cast_kernel's launch shape (0: not derived yet)
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
@@ -638,8 +640,12 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   if (pt->cast_blocks == 0 || pt->cast_depth != depth) {
     int cus = 0;
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
-    const size_t per_wave = (size_t)depth * 3u * 64u * sizeof(uint32_t);
+    // 13 frames of 12 bytes x 64 lanes: 16 waves per CU (what the kernel's registers allow) fit into the 160 KB
+    const uint32_t lds_max = getenv("SRT_CAST_LDS_FRAMES") ? (uint32_t)atoi(getenv("SRT_CAST_LDS_FRAMES")) : 13u;
+    const uint32_t lds_frames = depth < lds_max ? depth : (lds_max < 1u ? 1u : lds_max);
+    const size_t per_wave = (size_t)lds_frames * 3u * 64u * sizeof(uint32_t);
     int best_waves = 0;
+    pt->cast_blocks = 0;
     for (int w : {4, 2, 1}) {
       const size_t lds = per_wave * (size_t)w;
       if (lds > 160u * 1024u) continue;
@@ -649,15 +655,15 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       if (per_cu * w > best_waves) { best_waves = per_cu * w; pt->cast_threads = 64 * w; pt->cast_blocks = per_cu * cus; pt->cast_lds = lds; }
     }
     if (best_waves == 0) return srt::fail(SRT_ERR_UNSUPPORTED, "the ray-cast kernel's traversal stack (%u frames per lane) does not fit into LDS", depth);
-    pt->cast_depth = depth;
+    pt->cast_depth = depth; pt->cast_lds_frames = lds_frames;
     SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_CAST_STATS") && !pt->d_cast_stats) {
       SRT_HIP(hipMalloc(&pt->d_cast_stats, CS_COUNT * sizeof(unsigned long long)));
       SRT_HIP(hipMemset(pt->d_cast_stats, 0, CS_COUNT * sizeof(unsigned long long)));
     }
     if (pt->d_cast_stats) SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
-    if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u frames per lane), %d waves/CU\n",
-                                     pt->cast_blocks, pt->cast_threads, pt->cast_lds, depth, best_waves);
+    if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u of %u frames per lane), %d waves/CU\n",
+                                     pt->cast_blocks, pt->cast_threads, pt->cast_lds, lds_frames, depth, best_waves);
   }
   // the logic kernel: 1024-thread blocks; the streamed sweeps keep their per-wave slots in LDS (16 waves)
   const size_t nq = (trav == 4 && F.use_bvh) ? F.wave_tlas.size() : 0;
@@ -673,6 +679,8 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   if (!B.d_sc) SRT_HIP(hipMalloc(&B.d_sc, sizeof(StreamCounters)));
+  const size_t spill_words = (size_t)(depth - pt->cast_lds_frames) * 3u * (size_t)pt->cast_blocks * (size_t)pt->cast_threads;
+  if (spill_words && (st = ensure(&B.d_cast_spill, &B.cast_spill_words, spill_words)) != SRT_OK) return st;
   const uint32_t shadow_batches = (uint32_t)((F.delta_lights.size() + 2) / 3);
   const DScene DS = device_scene(pt);
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
@@ -714,7 +722,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       const uint64_t gens = ((uint64_t)P.total_units * M + nlanes - 1) / nlanes + M + 2;
       CastParams C{};
       C.ray_o = B.d_ray_o; C.ray_d = B.d_ray_d; C.ray_id = B.d_ray_id; C.hits = B.d_hits; C.nlanes = nlanes;
-      C.depth = depth; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
+      C.depth = depth; C.lds_frames = pt->cast_lds_frames; C.spill = B.d_cast_spill; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
       C.walk_nr = trav == 4 ? burst : 0u;
       for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];
       C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 8u;
@@ -835,7 +843,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     for (auto& kv : pt->epoch_buffers) {
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
-      (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id);
+      (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id); (void)hipFree(kv.second.d_cast_spill);
       (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc); (void)hipFree(kv.second.d_block_counters);
     }
     for (auto& v : {&pt->timed, &pt->spare, &pt->stream_timed[0], &pt->stream_timed[1], &pt->stream_timed[2]})

@@ -108,6 +108,14 @@ SRT_DEV void flat_begin(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 
 // ---- the steps of the walk; each requires the state named in its comment ----
 
 // mode == NODE, cur >= 0: an interior record of the current tree.
+// NO FRAME when only one child box is hit, the other child is an interior node and the ray's reciprocal direction is
+// finite.  The reference would come back to that other child iff the hit child's subtree reports a hit (cur_far_t =
+// dist_bounds, student/bvh.inl:205-216) and test the other child's two boxes; they lie inside a box the ray's line has just
+// missed (a node's box is the exact min/max union of its primitives' boxes, so child boxes nest bit for bit), and with
+// finite reciprocals every slab product of BBox::hit is monotone in the box bounds (fp subtraction and multiplication by a
+// fixed finite factor are monotone; no 0 * inf), so both tests fail as well, find_closest_hit returns "no hit" there, and
+// Trace::min(hit, no hit) keeps the hit: the node's result IS the hit child's.  A leaf on the other side is different -
+// its primitives would be tested whatever their box says - and keeps its frame.  Saves the push, the pop and the visit.
 template <typename StackT>
 SRT_DEV void flat_interior(FlatState& F, const StackT& stack, const DScene& S) {
   const WaveInterior* __restrict__ rp = F.level ? (S.blas_recs + F.rec_base) : S.wave_tlas;
@@ -120,12 +128,16 @@ SRT_DEV void flat_interior(FlatState& F, const StackT& stack, const DScene& S) {
     const int32_t rref = F.level ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
     const bool hb = hl && hr;
     const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
-    FlatFrame f;
-    f.second = cl ? rref : lref;
-    f.a = hb ? (cl ? t2x : t1x) : F.b0;        // cur_far_t: the other child's times, or ray.dist_bounds
-    f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : F.b1);
-    f.fl = hb ? 1u : 0u;
-    stack.store(F.sp++, f);
+    const int32_t far_ref = cl ? rref : lref;
+    const bool inv_finite = finite_f(F.cinv.x) && finite_f(F.cinv.y) && finite_f(F.cinv.z);
+    if (hb || far_ref < 0 || !inv_finite) {
+      FlatFrame f;
+      f.second = far_ref;
+      f.a = hb ? (cl ? t2x : t1x) : F.b0;      // cur_far_t: the other child's times, or ray.dist_bounds
+      f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : F.b1);
+      f.fl = hb ? 1u : 0u;
+      stack.store(F.sp++, f);
+    }
     F.cur = cl ? lref : rref;
     F.tx = cl ? t1x : t2x;
     F.ty = cl ? t1y : t2y;

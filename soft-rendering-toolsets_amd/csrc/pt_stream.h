@@ -49,13 +49,24 @@ enum {
 // 12-byte frames in LDS.  Word 0 holds the farther child's reference and "hitboth" until the nearer child has returned, then
 // the nearer child's object slot and hit flag (the reference is dead by then): payload << 2 | near_done << 1 | flag.
 // References: interior rank < 2^29, leaf ~(first << 3 | count) > -2^29 (checked on the host).
+// The first `k` frames of a lane live in LDS, deeper ones in a per-lane column of global memory (`g`, frame i word j at
+// g[((i - k) * 3 + j) * gstride]): with the childless-frame rule of flat_interior a walk rarely gets that deep, and LDS sized
+// for the tree's full depth is what limited the kernel's waves per CU.
 struct LdsStack {
   uint32_t* w;   // this lane's column: word k of frame i at w[(i * 3 + k) * 64]
+  uint32_t* g;
+  int k;
+  uint32_t gstride;
   SRT_DEV FlatFrame load(int i) const {
-    const uint32_t w0 = w[(i * 3 + 0) * 64];
+    uint32_t w0, w1, w2;
+    if (i < k) { w0 = w[(i * 3 + 0) * 64]; w1 = w[(i * 3 + 1) * 64]; w2 = w[(i * 3 + 2) * 64]; }
+    else {
+      const size_t at = (size_t)(i - k) * 3u * gstride;
+      w0 = g[at]; w1 = g[at + gstride]; w2 = g[at + 2u * (size_t)gstride];
+    }
     FlatFrame f;
-    f.a = __uint_as_float(w[(i * 3 + 1) * 64]);
-    f.b = w[(i * 3 + 2) * 64];
+    f.a = __uint_as_float(w1);
+    f.b = w2;
     const bool near_done = (w0 & 2u) != 0;
     f.second = near_done ? 0 : ((int32_t)w0 >> 2);
     f.fl = near_done ? (2u | ((w0 & 1u) << 2) | ((w0 >> 2) << 3)) : (w0 & 1u);
@@ -63,9 +74,12 @@ struct LdsStack {
   }
   SRT_DEV void store(int i, const FlatFrame& f) const {
     const bool near_done = (f.fl & 2u) != 0;
-    w[(i * 3 + 0) * 64] = near_done ? (((f.fl >> 3) << 2) | 2u | ((f.fl >> 2) & 1u)) : (((uint32_t)f.second << 2) | (f.fl & 1u));
-    w[(i * 3 + 1) * 64] = __float_as_uint(f.a);
-    w[(i * 3 + 2) * 64] = f.b;
+    const uint32_t w0 = near_done ? (((f.fl >> 3) << 2) | 2u | ((f.fl >> 2) & 1u)) : (((uint32_t)f.second << 2) | (f.fl & 1u));
+    if (i < k) { w[(i * 3 + 0) * 64] = w0; w[(i * 3 + 1) * 64] = __float_as_uint(f.a); w[(i * 3 + 2) * 64] = f.b; }
+    else {
+      const size_t at = (size_t)(i - k) * 3u * gstride;
+      g[at] = w0; g[at + gstride] = __float_as_uint(f.a); g[at + 2u * (size_t)gstride] = f.b;
+    }
   }
 };
 
@@ -84,7 +98,9 @@ struct CastParams {
   uint32_t gen;
   const uint32_t* nrays;     // rays of this generation
   uint32_t* head;            // queue head of this generation
-  uint32_t depth;            // frames per lane
+  uint32_t depth;            // frames a lane may need
+  uint32_t lds_frames;       // ... of which this many are in LDS,
+  uint32_t* spill;           // the others here: [frame - lds_frames][word][thread of the launch]            // frames per lane
   uint32_t fetch_min;        // idle lanes of a wave that trigger a fetch
   uint32_t interior_min;     // (unused by the phase scheduler; kept for experiments)
   uint32_t leaf_min;         // lanes waiting at BVH<Triangle> leaves that make the wave run the leaf phase
@@ -154,45 +170,6 @@ __global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_c
 enum { CS_OUTER = 0, CS_FETCH, CS_INTERIOR_TRIPS, CS_INTERIOR_LANES, CS_LEAF_TRIPS, CS_LEAF_LANES, CS_LEAF_TRIS, CS_OBJECT_TRIPS, CS_OBJECT_LANES,
        CS_T_FETCH, CS_T_INTERIOR, CS_WALKING_LANES, CS_T_LEAF, CS_T_OBJECT, CS_COUNT };
 
-// An interior record (flat_interior, pt_flat.h) with one addition: NO FRAME when only one child box is hit, the other child is
-// an interior node and the ray's reciprocal direction is finite.  The reference would come back to that other child iff the
-// hit child's subtree reports a hit (cur_far_t = dist_bounds, student/bvh.inl:205-216) and test the other child's two boxes;
-// they lie inside a box the ray's line has just missed, and with finite reciprocals every slab product of BBox::hit is
-// monotone in the box bounds (fp subtraction and multiplication by a fixed finite factor are monotone, no 0 * inf), so both
-// tests fail as well, find_closest_hit returns "no hit" there, and Trace::min(hit, no hit) keeps the hit: the node's result
-// IS the hit child's.  (A leaf on the other side is different - its triangles would be tested whatever their box says - and
-// keeps its frame.)  Saves the push, the pop and the wasted visit; results unchanged bit for bit.
-template <typename StackT>
-SRT_DEV void cast_interior(FlatState& F, const StackT& stack, const DScene& S) {
-  const WaveInterior* __restrict__ rp = F.level ? (S.blas_recs + F.rec_base) : S.wave_tlas;
-  const WaveInterior W = rp[F.cur];
-  float t1x = F.tx, t1y = F.ty, t2x = F.tx, t2y = F.ty;
-  const bool hl = box_hit_rec(W.boxl, F.co, F.cinv, t1x, t1y);
-  const bool hr = box_hit_rec(W.boxr, F.co, F.cinv, t2x, t2y);
-  if (hl || hr) {
-    const int32_t lref = F.level ? W.l_ref : flat_tlas_ref(W.l_ref, W.l_cnt);
-    const int32_t rref = F.level ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
-    const bool hb = hl && hr;
-    const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
-    const int32_t far_ref = cl ? rref : lref;
-    const bool inv_finite = finite_f(F.cinv.x) && finite_f(F.cinv.y) && finite_f(F.cinv.z);
-    if (hb || far_ref < 0 || !inv_finite) {
-      FlatFrame f;
-      f.second = far_ref;
-      f.a = hb ? (cl ? t2x : t1x) : F.b0;      // cur_far_t: the other child's times, or ray.dist_bounds
-      f.b = __float_as_uint(hb ? (cl ? t2y : t1y) : F.b1);
-      f.fl = hb ? 1u : 0u;
-      stack.store(F.sp++, f);
-    }
-    F.cur = cl ? lref : rref;
-    F.tx = cl ? t1x : t2x;
-    F.ty = cl ? t1y : t2y;
-  } else {
-    F.ret = flat_no_hit();
-    F.mode = FM_UNWIND;
-  }
-}
-
 // One pop: the top frame of a lane in FM_UNWIND - the visit rule for the farther child, or Trace::min of the two children
 // (flat_pop) - or, with no frame of the current tree left, the end of that tree: a mesh's tree hands over to the object
 // phase (Object::hit is finished there), the top-level tree finishes the ray.
@@ -230,7 +207,8 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
     return;
   }
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-  const LdsStack stack{cast_lds + (size_t)wave * P.depth * 3u * 64u + (uint32_t)lane};
+  const LdsStack stack{cast_lds + (size_t)wave * P.lds_frames * 3u * 64u + (uint32_t)lane,
+                       P.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x, (int)P.lds_frames, gridDim.x * blockDim.x};
   FlatState F;                                            // F.mode == FM_DONE: the lane is idle
   bool have = false;                                      // the lane holds a finished ray whose result is not written yet
   bool exhausted = false;                                 // the queue has nothing left for this wave
@@ -309,7 +287,7 @@ __global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
       if (F.mode == FM_UNWIND) {
         cast_unwind_step(F, stack);
         if (P.pops > 1u && F.mode == FM_UNWIND) cast_unwind_step(F, stack);   // (a second pop costs less than another trip)
-      } else if (at_walk) cast_interior(F, stack, S);
+      } else if (at_walk) flat_interior(F, stack, S);
       cast_enter_leaf_objects(F);
       CAST_STAT(CS_T_INTERIOR, __builtin_readcyclecounter() - t0);
     } else if (run_obj) {
