@@ -197,8 +197,11 @@ SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
 //   object  Object::hit: ray -> object space, sphere / one-leaf mesh on the spot, or into / out of a mesh's tree.
 // The two expensive phases run when enough lanes have piled up in front of them (or nothing else can run), so they execute
 // with those lanes instead of with whoever happens to be there.
+#ifndef SRT_CAST_OCC
+#define SRT_CAST_OCC 4
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void pt_cast_kernel(DScene S, CastParams P) {
+__global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
   const uint32_t nrays = *P.nrays;
   if (nrays == 0u) {

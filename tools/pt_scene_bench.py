@@ -26,12 +26,15 @@ imgs = []
 modes = tuple(int(m) for m in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1, 2, 4, 5, 6)
 for mode in modes:
     pt.set_kernel(mode)
-    pt.render_epoch(0, 0, 1)
+    pt.render_epoch(0, 0, spp if os.environ.get('SRT_WARM_FULL') else 1)
     pt.ray_count(reset=True)
     t = time.perf_counter(); img = pt.render_epoch(0, 0, spp); dt = time.perf_counter() - t
     rays, cams = pt.ray_count()
     imgs.append(img)
     print(f"mode {mode}: {dt*1e3:.1f} ms, {rays/dt/1e6:.0f} Mrays/s, {rays/cams:.2f} rays/sample")
+    if os.environ.get("SRT_STREAM_TIMES") and pt.kernel_form() >= 3:
+        pt.stream_times(True); pt.render_epoch(0, 0, spp); ms, g = pt.stream_times(False)
+        print(f"   per-kernel (serialised by the timing events): {ms}, {g} generations")
 if os.environ.get("SRT_ELIDE"):
     pt.set_elision(True)
     for mode in modes:
