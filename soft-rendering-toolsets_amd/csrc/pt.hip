@@ -547,7 +547,8 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   // every continuous BSDF Lambertian (pt_wave.h)
   const bool two = elision_provable(pt) && !stamp && trav != 2;
   const uint32_t burst = two ? 2u : kBurst;
-  const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);  // 4 waves x (Q - 1) x rays x 2 fields
+  const size_t lds = (size_t)4 * (nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float)   // 4 waves x (Q - 1) x rays x 2 fields
+                     + (cold_in_lds(trav) ? (size_t)kColdWords * 256 * sizeof(uint32_t) : 0); // + the lanes' cold path state
   const void* kern = two ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false, 2> : (const void*)pt_wave_kernel<false, 1, false, 2>) : stamp ? (trav == 0 ? (const void*)pt_wave_kernel<true, 0, false, 3> : trav == 1 ? (const void*)pt_wave_kernel<true, 1, false, 3> : (const void*)pt_wave_kernel<true, 2, false, 3>)
                      : dl  ? (trav == 0 ? (const void*)pt_wave_kernel<false, 0, true, 3> : (const void*)pt_wave_kernel<false, 1, true, 3>)
                            : (trav == 0 ? (const void*)pt_wave_kernel<false, 0, false, 3> : trav == 1 ? (const void*)pt_wave_kernel<false, 1, false, 3> : (const void*)pt_wave_kernel<false, 2, false, 3>);
@@ -997,6 +998,7 @@ int srt_pt_set_params(srt_pt* pt, uint32_t width, uint32_t height, uint32_t max_
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_params: NULL context");
   if (!width || !height) return srt::fail(SRT_ERR_INVALID, "image must be at least 1x1 (got %ux%u)", width, height);
   if ((uint64_t)width * height > 0x7fffffffull) return srt::fail(SRT_ERR_UNSUPPORTED, "image larger than 2^31 pixels");
+  if (width > 65535u || height > 65535u) return srt::fail(SRT_ERR_UNSUPPORTED, "image sides above 65535 are not supported (got %ux%u)", width, height);
   if (max_depth > (uint32_t)kMaxPathDepth) return srt::fail(SRT_ERR_UNSUPPORTED, "max_depth %u > %d is not supported", max_depth, kMaxPathDepth);
   pt->w = width; pt->h = height; pt->max_depth = max_depth;
   update_tiling(pt);

@@ -61,7 +61,8 @@ struct WaveParams {
   uint32_t total_units;      // pixels * (groups3 + singles)
   uint32_t nlanes;           // threads of the whole grid (record scratch stride)
   float* sample_out;         // [unit] float4 {r, g, b, 0}: one aligned 16-byte store per finished sample
-  float* records;            // float4 [(level * 2 + half) * nlanes + lane]: a bounce record is two coalesced 16-byte stores per lane
+  float* records;            // float4 [(lane * kMaxPathDepth + level) * 2 + half]: a lane's records are one contiguous run (a bounce = 32 bytes,
+                             // four bounces = one 128-byte line), so the read-back at the end of a path fetches the lines it uses and nothing else
                              // (half 0 = {direct rgb, discrete} when the bounce's direct light is known, half 1 = {atten rgb, 1/pdf} when it is shaded)
   unsigned long long* queue_head;   // next unit to hand out (zeroed before every launch)
   unsigned long long* ray_counter;  // scene.hit calls as the reference issues them, accumulated across launches
@@ -424,6 +425,30 @@ enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_T
 // point_lighting == 0, i.e. +0 for any finite direct, and a NaN direct comes with a NaN second term), so only its random
 // draws are kept and a bounce batch is {MIS direct ray | the direct ray of a discrete BSDF, indirect ray}; units are
 // pairs of samples.  Rays are counted as the reference issues them (P.ray_counter); P.elided_counter counts the ones not traced.
+// A dword of per-lane path state that is touched a few times per path (pixel, sample window, parked camera hits).  The
+// persistent sweep kernel keeps these in LDS, [variable][thread]: it needs ~150 VGPRs and runs with 128 (4 waves / SIMD is
+// worth 11 % over 3), so what does not fit goes to scratch, and scratch lines that fall out of L2 were most of the kernel's
+// memory traffic (profiles/README.md); a value parked in LDS costs a ds_read where it is used and no traffic at all.
+template <bool IN_LDS> struct ColdU32;
+template <> struct ColdU32<false> {
+  uint32_t v;
+  SRT_DEV void bind(uint32_t*) {}
+  SRT_DEV operator uint32_t() const { return v; }
+  SRT_DEV ColdU32& operator=(uint32_t x) { v = x; return *this; }
+  SRT_DEV ColdU32& operator=(const ColdU32& o) { v = o.v; return *this; }
+};
+template <> struct ColdU32<true> {
+  uint32_t* p;
+  SRT_DEV void bind(uint32_t* at) { p = at; }
+  SRT_DEV operator uint32_t() const { return *p; }
+  SRT_DEV ColdU32& operator=(uint32_t x) { *p = x; return *this; }
+  SRT_DEV ColdU32& operator=(const ColdU32& o) { *p = *o.p; return *this; }   // (the VALUE: the default would rebind)
+};
+// Four words per lane is what the LDS has left at 16 waves / CU next to the sweep slots of the Cornell box's seven-node BVH<Object>:
+// pixel (x | y << 16), local pixel index, sample window (first | current << 16 | count << 30), the first parked camera hit.
+constexpr int kColdWords = 4;
+__host__ __device__ constexpr bool cold_in_lds(int trav) { return trav == 0; }
+
 template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_WAVE_OCC
 #define SRT_WAVE_OCC 4
@@ -482,7 +507,9 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   //   after step q            field 0 = cur_far_t.x of node q        (tin is dead once read)
   //   after bottom-up step q  field 0 = ret.dist, field 1 = ret.id   (read by the parent)
   // The root (q = 0) has no slot: it receives no `times` and nobody reads its result; its cur_far_t.x stays in registers.
-  float* wl = lds_f + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;
+  constexpr bool COLD = cold_in_lds(TRAV);
+  uint32_t* const cold = reinterpret_cast<uint32_t*>(lds_f) + threadIdx.x;           // [variable][thread of the block]
+  float* wl = lds_f + (COLD ? kColdWords * 256 : 0) + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;
 #define SLOT(q, r, f) wl[((((q) - 1) * NR + (r)) * 2 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
@@ -493,12 +520,19 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   // ---- persistent per-lane path state ----
   bool alive = false;                                    // the lane owns a unit that is not finished yet
   bool burst = false;                                    // the batch in flight is a camera burst (else a bounce batch)
-  uint32_t px = 0, py = 0;                               // pixel of the unit
-  uint32_t s_first = 0, s_count = 0, s_cur = 0;          // samples [s_first, s_first + s_count) of the launch; current one
-  uint32_t pixel_slot = 0;                               // local pixel index (sample_out addressing)
-  uint32_t pend[NR - 1];                                 // parked camera hits of samples s_cur+1, s_cur+2 (burst order)
-#pragma unroll
-  for (int j = 0; j < NR - 1; j++) pend[j] = kRetMiss;
+  ColdU32<COLD> pxy;                                     // pixel of the unit: x | y << 16 (srt_pt_set_params: both < 65536)
+  ColdU32<COLD> samp;                                    // samples [first, first + count) of the launch and the current one:
+                                                         // first | current << 16 | count << 30 (the SW_SAMPLES word)
+  ColdU32<COLD> pixel_slot;                              // local pixel index (sample_out addressing)
+  ColdU32<COLD> pend0;                                   // parked camera hits of samples current+1, current+2 (burst order):
+  uint32_t pend1 = kRetMiss;                             // the first in LDS with the others, the second (NR == 3) in a register
+  pxy.bind(cold + 0 * 256); samp.bind(cold + 1 * 256); pixel_slot.bind(cold + 2 * 256); pend0.bind(cold + 3 * 256);
+  pxy = 0u; samp = 0u; pixel_slot = 0u; pend0 = kRetMiss;
+#define PX_ ((uint32_t)pxy & 0xffffu)
+#define PY_ ((uint32_t)pxy >> 16)
+#define S_FIRST_ ((uint32_t)samp & 0xffffu)
+#define S_CUR_ (((uint32_t)samp >> 16) & 0x3fffu)
+#define S_COUNT_ ((uint32_t)samp >> 30)
   uint32_t depth = 0, level = 0;
   Rng rng;
   rng.state = 0; rng.inc = 1; rng.draws = 0;
@@ -536,6 +570,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   // consumes the hits of the batch emitted by the previous generation (step 3 as it stands), pass 1 refills idle slots,
   // appends the next batch's rays to the queue and saves the state.
 #define ST(w) P.state[(size_t)(w) * P.nlanes + lane_global]
+#define REC(lev, half) reinterpret_cast<float4*>(P.records)[((size_t)lane_global * kMaxPathDepth + (size_t)(lev)) * 2u + (half)]
   uint32_t emit_mask = 0;                                // queue slots of this lane that carry a ray / walk request for the next cast
   if constexpr (STREAM) {
     if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
@@ -545,13 +580,12 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
       burst = (fw & 2u) != 0; actA = (fw & 4u) != 0; actB = (fw & 8u) != 0; discrete = (fw & 16u) != 0;
       sh_phase = (fw & 32u) != 0; sa1 = (fw & 64u) != 0; sa2 = (fw & 128u) != 0;
       level = (fw >> 8) & 0xffu; depth = (fw >> 16) & 0xffu;
-      px = ST(SW_PX); py = ST(SW_PY); pixel_slot = ST(SW_PIXEL_SLOT);
-      const uint32_t sw = ST(SW_SAMPLES);
-      s_first = sw & 0xffffu; s_cur = (sw >> 16) & 0x3fffu; s_count = sw >> 30;
-      pend[0] = ST(SW_PEND0);
-      if (NR > 2) pend[NR - 2] = ST(SW_PEND1);
+      pxy = ST(SW_PX) | (ST(SW_PY) << 16); pixel_slot = ST(SW_PIXEL_SLOT);
+      samp = ST(SW_SAMPLES);
+      pend0 = ST(SW_PEND0);
+      if (NR > 2) pend1 = ST(SW_PEND1);
       rng.state = (uint64_t)ST(SW_RNG_LO) | ((uint64_t)ST(SW_RNG_HI) << 32);
-      rng.inc = (((((uint64_t)(py * S.w + px)) << 32) | (uint64_t)(P.sample_base + s_cur)) << 1) | 1ull;   // Rng::key's increment
+      rng.inc = (((((uint64_t)(PY_ * S.w + PX_)) << 32) | (uint64_t)(P.sample_base + S_CUR_)) << 1) | 1ull;   // Rng::key's increment
       org = v3(__uint_as_float(ST(SW_ORG)), __uint_as_float(ST(SW_ORG + 1)), __uint_as_float(ST(SW_ORG + 2)));
       d[C] = v3(__uint_as_float(ST(SW_DC)), __uint_as_float(ST(SW_DC + 1)), __uint_as_float(ST(SW_DC + 2)));
       cb0 = __uint_as_float(ST(SW_CB0)); cb1 = __uint_as_float(ST(SW_CB1));
@@ -577,10 +611,10 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
                    (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16);
     ST(SW_EMIT) = emit_mask | (alive ? 0x80000000u : 0u);   // (bit 31: the slot is alive - a generation without requests need not be the last)
     if (alive) {
-      ST(SW_PX) = px; ST(SW_PY) = py; ST(SW_PIXEL_SLOT) = pixel_slot;
-      ST(SW_SAMPLES) = s_first | (s_cur << 16) | (s_count << 30);
-      ST(SW_PEND0) = pend[0];
-      if (NR > 2) ST(SW_PEND1) = pend[NR - 2];
+      ST(SW_PX) = PX_; ST(SW_PY) = PY_; ST(SW_PIXEL_SLOT) = pixel_slot;
+      ST(SW_SAMPLES) = samp;
+      ST(SW_PEND0) = pend0;
+      if (NR > 2) ST(SW_PEND1) = pend1;
       ST(SW_RNG_LO) = (uint32_t)rng.state; ST(SW_RNG_HI) = (uint32_t)(rng.state >> 32);
       ST(SW_ORG) = __float_as_uint(org.x); ST(SW_ORG + 1) = __float_as_uint(org.y); ST(SW_ORG + 2) = __float_as_uint(org.z);
       ST(SW_DC) = __float_as_uint(d[C].x); ST(SW_DC + 1) = __float_as_uint(d[C].y); ST(SW_DC + 2) = __float_as_uint(d[C].z);
@@ -658,11 +692,9 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (x < img_w && y < img_h) {                   // padding pixels of edge tiles are never read
           alive = true;
           burst = true;
-          px = x; py = y;
+          pxy = x | (y << 16);
           pixel_slot = u_pixel;
-          s_first = u_first;
-          s_count = u_count;
-          s_cur = s_first;
+          samp = u_first | (u_first << 16) | (u_count << 30);
           level = 0;
           depth = S.max_depth;
           // camera rays of the unit's samples (trace_pixel, student/pathtracer.cpp:26-31); absent samples repeat the first
@@ -671,7 +703,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           const uint32_t sample_base = opq(P.sample_base);
 #pragma unroll
           for (int j = 0; j < NR; j++) {
-            const uint32_t sj = s_first + ((uint32_t)j < s_count ? (uint32_t)j : 0u);
+            const uint32_t sj = u_first + ((uint32_t)j < u_count ? (uint32_t)j : 0u);
             rng.key(seed, y * img_w + x, sample_base + sj);
             const float jx = rng.unit() * 1.0f;
             const float jy = rng.unit() * 1.0f;
@@ -679,8 +711,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             org = cam.o;                                // the same for every camera ray (iview * origin)
             d[j] = cam.d; cb0 = cam.b0; cb1 = cam.b1;
           }
-          actA = s_count > 1;                           // slot usage of a burst: ray j exists iff j < s_count
-          actB = s_count > 2;
+          actA = u_count > 1;                           // slot usage of a burst: ray j exists iff j < count
+          actB = u_count > 2;
           need_begin = true;
         } else {
           units_finished++;                             // a padding pixel of an edge tile: nothing to render
@@ -963,7 +995,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             radiance = radiance + dA_keep;
             radiance = radiance - dA_keep;
             radiance = radiance + d6_keep;
-            reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+            REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
             sh_phase = false;
             chit = held_chit;
             d[C] = dC_keep;
@@ -975,7 +1007,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         // burst order: slot 0 = sample s_first (continues now), the other slots = the next samples (parked)
         chit = pack_ret(res[0], oshift);
 #pragma unroll
-        for (int j = 0; j < NR - 1; j++) pend[j] = pack_ret(res[j + 1], oshift);
+        for (int j = 0; j < NR - 1; j++) { const uint32_t pr = pack_ret(res[j + 1], oshift); if (j == 0) pend0 = pr; else pend1 = pr; }
         if constexpr (DL) {
           if (S.env_type != 0u) {
             // a camera ray that leaves the scene sees the environment light (student/pathtracer.cpp:182-188): remember
@@ -984,7 +1016,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             if (!res[0].hit && (S.env_type != 2u || d[0].y > 0.0f)) chit = kRetMissEnv;
 #pragma unroll
             for (int j = 0; j < NR - 1; j++)
-              if (!res[j + 1].hit && (S.env_type != 2u || d[j + 1].y > 0.0f)) pend[j] = kRetMissEnv;
+              if (!res[j + 1].hit && (S.env_type != 2u || d[j + 1].y > 0.0f)) { if (j == 0) pend0 = kRetMissEnv; else pend1 = kRetMissEnv; }
           }
         }
       } else if constexpr (NR == 2) {
@@ -1000,7 +1032,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           const Spec d6 = (e0 * att) * (1.0f / pdf);
           radiance = radiance + d6;                     // ((0 + direct) - direct) + d6
         }
-        reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+        REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
         chit = pack_ret(res[C], oshift);
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             }
           }
           if (!(DL && sh_phase)) {
-            reinterpret_cast<float4*>(P.records)[(size_t)(level - 1) * 2 * P.nlanes + lane_global] = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+            REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
           }
         }
         chit = pack_ret(res[C], oshift);
@@ -1063,10 +1095,10 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           if (S.env_type == 3u) {                         // Env_Map::evaluate(ray.dir) of the sample's camera ray
             Rng cr;
             const uint32_t img_w = opq(S.w), img_h = opq(S.h);
-            cr.key(opq(P.seed), py * img_w + px, opq(P.sample_base) + s_cur);
+            cr.key(opq(P.seed), PY_ * img_w + PX_, opq(P.sample_base) + S_CUR_);
             const float jx = cr.unit() * 1.0f;
             const float jy = cr.unit() * 1.0f;
-            const Ray cam = camera_ray(opq(S.cam), ((float)px + jx) / (float)img_w, ((float)py + jy) / (float)img_h);
+            const Ray cam = camera_ray(opq(S.cam), ((float)PX_ + jx) / (float)img_w, ((float)PY_ + jy) / (float)img_h);
             e = env_map_evaluate(S, cam.d);
           }
         }
@@ -1079,8 +1111,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (!terminal) { need_shade = true; break; }
         Spec L = spec(0, 0, 0);
         for (int k = (int)level - 1; k >= 0; k--) {
-          const float4 r0 = reinterpret_cast<const float4*>(P.records)[(size_t)k * 2 * P.nlanes + lane_global];
-          const float4 r1 = reinterpret_cast<const float4*>(P.records)[((size_t)k * 2 + 1) * P.nlanes + lane_global];
+          const float4 r0 = REC(k, 0);
+          const float4 r1 = REC(k, 1);
           const Spec dk = spec(r0.x, r0.y, r0.z);
           const Spec ak = spec(r1.x, r1.y, r1.z);
           Spec ind = (r0.w != 0.0f) ? (L * ak) : ((L * ak) * r1.w);
@@ -1088,13 +1120,12 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           L = dk + ind;
         }
         const Spec out = ((level == 0) ? e : spec(0, 0, 0)) + L;
-        reinterpret_cast<float4*>(P.sample_out)[(size_t)s_cur * P.npix + pixel_slot] = make_float4(out.r, out.g, out.b, 0.0f);
+        reinterpret_cast<float4*>(P.sample_out)[(size_t)S_CUR_ * P.npix + pixel_slot] = make_float4(out.r, out.g, out.b, 0.0f);
         // next sample of the unit: its camera hit is already known
-        s_cur++;
-        if (s_cur < s_first + s_count) {
-          chit = pend[0];
-#pragma unroll
-          for (int j = 0; j + 1 < NR - 1; j++) pend[j] = pend[j + 1];
+        samp = (uint32_t)samp + (1u << 16);
+        if (S_CUR_ < S_FIRST_ + S_COUNT_) {
+          chit = pend0;
+          if (NR > 2) pend0 = pend1;
           level = 0;
           depth = S.max_depth;
           burst = true;                                 // "the ray that led here was a camera ray"
@@ -1112,10 +1143,10 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (level == 0) {
           // a camera ray: regenerate it (and the RNG position after its two jitter draws) from the sample index
           const uint32_t img_w = opq(S.w), img_h = opq(S.h);
-          rng.key(opq(P.seed), py * img_w + px, opq(P.sample_base) + s_cur);
+          rng.key(opq(P.seed), PY_ * img_w + PX_, opq(P.sample_base) + S_CUR_);
           const float jx = rng.unit() * 1.0f;
           const float jy = rng.unit() * 1.0f;
-          ray = camera_ray(opq(S.cam), ((float)px + jx) / (float)img_w, ((float)py + jy) / (float)img_h);
+          ray = camera_ray(opq(S.cam), ((float)PX_ + jx) / (float)img_w, ((float)PY_ + jy) / (float)img_h);
         }
         burst = false;
         Surface sf = surface_of(S, ch, ray);
@@ -1147,7 +1178,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
         else s2 = scatter(m, out_dir, rng);
         const V3 world_in2 = frame_to_world(fr, s2.dir);
-        reinterpret_cast<float4*>(P.records)[((size_t)level * 2 + 1) * P.nlanes + lane_global] =
+        REC(level, 1) =
             make_float4(s2.atten.r, s2.atten.g, s2.atten.b, discrete ? 0.0f : (1.0f / pdf4));
         level++;
         depth--;
@@ -1171,6 +1202,12 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
 
 #undef SLOT
 #undef ST
+#undef REC
+#undef PX_
+#undef PY_
+#undef S_FIRST_
+#undef S_CUR_
+#undef S_COUNT_
   unsigned long long r = cnt.v[C_RAYS], rt = (NR == 3) ? cnt.v[C_RAYS] : traced;
   for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); }
   if constexpr (STREAM) {
