@@ -429,6 +429,7 @@ enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_T
 // persistent sweep kernel keeps these in LDS, [variable][thread]: it needs ~150 VGPRs and runs with 128 (4 waves / SIMD is
 // worth 11 % over 3), so what does not fit goes to scratch, and scratch lines that fall out of L2 were most of the kernel's
 // memory traffic (profiles/README.md); a value parked in LDS costs a ds_read where it is used and no traffic at all.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool IN_LDS> struct ColdU32;
 template <> struct ColdU32<false> {
   uint32_t v;
@@ -570,7 +571,11 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   // consumes the hits of the batch emitted by the previous generation (step 3 as it stands), pass 1 refills idle slots,
   // appends the next batch's rays to the queue and saves the state.
 #define ST(w) P.state[(size_t)(w) * P.nlanes + lane_global]
-#define REC(lev, half) reinterpret_cast<float4*>(P.records)[((size_t)lane_global * kMaxPathDepth + (size_t)(lev)) * 2u + (half)]
+// (non-temporal: a record is written once and read once, a sample is written once - they should not push the waves' scratch
+//  lines out of L2 on their way through)
+#define REC_AT(lev, half) (reinterpret_cast<f32x4*>(P.records) + (((size_t)lane_global * kMaxPathDepth + (size_t)(lev)) * 2u + (half)))
+#define REC_STORE(lev, half, x, y, z, w) __builtin_nontemporal_store(f32x4{x, y, z, w}, REC_AT(lev, half))
+#define REC_LOAD(lev, half) (*REC_AT(lev, half))
   uint32_t emit_mask = 0;                                // queue slots of this lane that carry a ray / walk request for the next cast
   if constexpr (STREAM) {
     if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
@@ -995,7 +1000,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             radiance = radiance + dA_keep;
             radiance = radiance - dA_keep;
             radiance = radiance + d6_keep;
-            REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+            REC_STORE(level - 1, 0, radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
             sh_phase = false;
             chit = held_chit;
             d[C] = dC_keep;
@@ -1032,7 +1037,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           const Spec d6 = (e0 * att) * (1.0f / pdf);
           radiance = radiance + d6;                     // ((0 + direct) - direct) + d6
         }
-        REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+        REC_STORE(level - 1, 0, radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
         chit = pack_ret(res[C], oshift);
       } else {
         if (actA) {                                     // sample_direct_lighting's arithmetic (student/pathtracer.cpp:78-172)
@@ -1061,7 +1066,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
             }
           }
           if (!(DL && sh_phase)) {
-            REC(level - 1, 0) = make_float4(radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
+            REC_STORE(level - 1, 0, radiance.r, radiance.g, radiance.b, discrete ? 1.0f : 0.0f);
           }
         }
         chit = pack_ret(res[C], oshift);
@@ -1111,8 +1116,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (!terminal) { need_shade = true; break; }
         Spec L = spec(0, 0, 0);
         for (int k = (int)level - 1; k >= 0; k--) {
-          const float4 r0 = REC(k, 0);
-          const float4 r1 = REC(k, 1);
+          const f32x4 r0 = REC_LOAD(k, 0);
+          const f32x4 r1 = REC_LOAD(k, 1);
           const Spec dk = spec(r0.x, r0.y, r0.z);
           const Spec ak = spec(r1.x, r1.y, r1.z);
           Spec ind = (r0.w != 0.0f) ? (L * ak) : ((L * ak) * r1.w);
@@ -1120,7 +1125,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           L = dk + ind;
         }
         const Spec out = ((level == 0) ? e : spec(0, 0, 0)) + L;
-        reinterpret_cast<float4*>(P.sample_out)[(size_t)S_CUR_ * P.npix + pixel_slot] = make_float4(out.r, out.g, out.b, 0.0f);
+        __builtin_nontemporal_store(f32x4{out.r, out.g, out.b, 0.0f}, reinterpret_cast<f32x4*>(P.sample_out) + ((size_t)S_CUR_ * P.npix + pixel_slot));
         // next sample of the unit: its camera hit is already known
         samp = (uint32_t)samp + (1u << 16);
         if (S_CUR_ < S_FIRST_ + S_COUNT_) {
@@ -1178,8 +1183,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
         else s2 = scatter(m, out_dir, rng);
         const V3 world_in2 = frame_to_world(fr, s2.dir);
-        REC(level, 1) =
-            make_float4(s2.atten.r, s2.atten.g, s2.atten.b, discrete ? 0.0f : (1.0f / pdf4));
+        REC_STORE(level, 1, s2.atten.r, s2.atten.g, s2.atten.b, discrete ? 0.0f : (1.0f / pdf4));
         level++;
         depth--;
         org = sf.position;
@@ -1202,7 +1206,9 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
 
 #undef SLOT
 #undef ST
-#undef REC
+#undef REC_AT
+#undef REC_STORE
+#undef REC_LOAD
 #undef PX_
 #undef PY_
 #undef S_FIRST_
