@@ -336,7 +336,7 @@ struct srt_pt {
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
-  uint32_t cast_lds_frames = 0;                                 // traversal frames per lane kept in LDS (the deeper ones: d_cast_spill)
+  const void* cast_kern = nullptr; uint32_t cast_lds_frames = 0;                                 // traversal frames per lane kept in LDS (the deeper ones: d_cast_spill)
   int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0; uint32_t cast_depth = 0;   // pt_cast_kernel's launch shape (0: not derived yet)
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
@@ -638,7 +638,10 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   int st;
   // the cast kernel's launch shape: frames per lane from the scene's tree depths, as many waves per CU as the LDS holds
   const uint32_t depth = (trav == 4 ? 0u : F.max_tlas_depth) + F.max_blas_depth + 1u;
-  if (pt->cast_blocks == 0 || pt->cast_depth != depth) {
+  const void* ckern = trav == 4 ? (const void*)pt_cast_kernel<false, true> : (const void*)pt_cast_kernel<false, false>;
+  const void* ckern_stats = trav == 4 ? (const void*)pt_cast_kernel<true, true> : (const void*)pt_cast_kernel<true, false>;
+  if (pt->cast_blocks == 0 || pt->cast_depth != depth || pt->cast_kern != ckern) {
+    pt->cast_kern = ckern;
     int cus = 0;
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
     // 13 frames of 12 bytes x 64 lanes: 16 waves per CU (what the kernel's registers allow) fit into the 160 KB
@@ -650,19 +653,19 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     for (int w : {4, 2, 1}) {
       const size_t lds = per_wave * (size_t)w;
       if (lds > 160u * 1024u) continue;
-      if (hipFuncSetAttribute((const void*)pt_cast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+      if (hipFuncSetAttribute(ckern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pt_cast_kernel<false>, 64 * w, lds) != hipSuccess || per_cu < 1) continue;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ckern, 64 * w, lds) != hipSuccess || per_cu < 1) continue;
       if (per_cu * w > best_waves) { best_waves = per_cu * w; pt->cast_threads = 64 * w; pt->cast_blocks = per_cu * cus; pt->cast_lds = lds; }
     }
     if (best_waves == 0) return srt::fail(SRT_ERR_UNSUPPORTED, "the ray-cast kernel's traversal stack (%u frames per lane) does not fit into LDS", depth);
     pt->cast_depth = depth; pt->cast_lds_frames = lds_frames;
-    SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
+    SRT_HIP(hipFuncSetAttribute(ckern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_CAST_STATS") && !pt->d_cast_stats) {
       SRT_HIP(hipMalloc(&pt->d_cast_stats, CS_COUNT * sizeof(unsigned long long)));
       SRT_HIP(hipMemset(pt->d_cast_stats, 0, CS_COUNT * sizeof(unsigned long long)));
     }
-    if (pt->d_cast_stats) SRT_HIP(hipFuncSetAttribute((const void*)pt_cast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
+    if (pt->d_cast_stats) SRT_HIP(hipFuncSetAttribute(ckern_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u of %u frames per lane), %d waves/CU\n",
                                      pt->cast_blocks, pt->cast_threads, pt->cast_lds, lds_frames, depth, best_waves);
   }
@@ -752,8 +755,9 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
         pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id);
         if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
         C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
-        if (pt->d_cast_stats) pt_cast_kernel<true><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
-        else pt_cast_kernel<false><<<dim3(pt->cast_blocks), dim3(pt->cast_threads), pt->cast_lds, s>>>(DS, C);
+        const dim3 kgrid(pt->cast_blocks), kblock(pt->cast_threads);
+        if (trav == 4) { if (pt->d_cast_stats) pt_cast_kernel<true, true><<<kgrid, kblock, pt->cast_lds, s>>>(DS, C); else pt_cast_kernel<false, true><<<kgrid, kblock, pt->cast_lds, s>>>(DS, C); }
+        else { if (pt->d_cast_stats) pt_cast_kernel<true, false><<<kgrid, kblock, pt->cast_lds, s>>>(DS, C); else pt_cast_kernel<false, false><<<kgrid, kblock, pt->cast_lds, s>>>(DS, C); }
         if ((st = stream_time_end(pt, s, 2)) != SRT_OK) return st;
       }
       if (pt->stream_timing) pt->stream_generations += gens;

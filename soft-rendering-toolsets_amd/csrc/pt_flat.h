@@ -116,16 +116,18 @@ SRT_DEV void flat_begin(FlatState& F, const DScene& S, V3 org, V3 d0, V3 d1, V3 
 // fixed finite factor are monotone; no 0 * inf), so both tests fail as well, find_closest_hit returns "no hit" there, and
 // Trace::min(hit, no hit) keeps the hit: the node's result IS the hit child's.  A leaf on the other side is different -
 // its primitives would be tested whatever their box says - and keeps its frame.  Saves the push, the pop and the visit.
-template <typename StackT>
+// (LEVEL: -1 the lane's own F.level; 1 the caller knows that every lane is inside a BVH<Triangle>.)
+template <typename StackT, int LEVEL = -1>
 SRT_DEV void flat_interior(FlatState& F, const StackT& stack, const DScene& S) {
-  const WaveInterior* __restrict__ rp = F.level ? (S.blas_recs + F.rec_base) : S.wave_tlas;
+  const bool blas = LEVEL == 1 || (LEVEL < 0 && F.level != 0u);
+  const WaveInterior* __restrict__ rp = blas ? (S.blas_recs + F.rec_base) : S.wave_tlas;
   const WaveInterior W = rp[F.cur];
   float t1x = F.tx, t1y = F.ty, t2x = F.tx, t2y = F.ty;
   const bool hl = box_hit_rec(W.boxl, F.co, F.cinv, t1x, t1y);
   const bool hr = box_hit_rec(W.boxr, F.co, F.cinv, t2x, t2y);
   if (hl || hr) {
-    const int32_t lref = F.level ? W.l_ref : flat_tlas_ref(W.l_ref, W.l_cnt);
-    const int32_t rref = F.level ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
+    const int32_t lref = blas ? W.l_ref : flat_tlas_ref(W.l_ref, W.l_cnt);
+    const int32_t rref = blas ? W.r_ref : flat_tlas_ref(W.r_ref, W.r_cnt);
     const bool hb = hl && hr;
     const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
     const int32_t far_ref = cl ? rref : lref;

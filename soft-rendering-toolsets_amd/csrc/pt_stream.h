@@ -173,8 +173,14 @@ enum { CS_OUTER = 0, CS_FETCH, CS_INTERIOR_TRIPS, CS_INTERIOR_LANES, CS_LEAF_TRI
 // One pop: the top frame of a lane in FM_UNWIND - the visit rule for the farther child, or Trace::min of the two children
 // (flat_pop) - or, with no frame of the current tree left, the end of that tree: a mesh's tree hands over to the object
 // phase (Object::hit is finished there), the top-level tree finishes the ray.
-template <typename StackT>
+// (WALK: every lane is inside a mesh's tree, which starts at frame 0.)
+template <bool WALK, typename StackT>
 SRT_DEV void cast_unwind_step(FlatState& F, const StackT& stack) {
+  if (WALK) {
+    if (F.sp != 0) flat_pop(F, stack);
+    else F.mode = FM_OBJECT;
+    return;
+  }
   if (flat_plain_frame(F)) flat_pop(F, stack);
   else if (F.level) F.mode = FM_OBJECT;
   else { F.res0 = F.ret; F.mode = FM_DONE; }
@@ -200,7 +206,8 @@ SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
 #ifndef SRT_CAST_OCC
 #define SRT_CAST_OCC 4
 #endif
-template <bool STATS>
+// WALK: the entries are walk requests of the streamed sweeps (P.walk_nr > 0) - no lane ever stands in the top-level tree.
+template <bool STATS, bool WALK>
 __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
   const uint32_t nrays = *P.nrays;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
         uint2 o;
         o.x = __float_as_uint(h.hit ? h.dist : 0.0f);
         o.y = h.hit ? ((h.obj << P.obj_shift) | h.tri) : 0xFFFFFFFFu;
-        if (P.walk_nr) o.y = h.hit ? h.tri : 0xFFFFFFFFu;
+        if (WALK) o.y = h.hit ? h.tri : 0xFFFFFFFFu;
         P.hits[my_id] = o;
         have = false;
       }
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
           my_id = P.ray_id[idx];
           const float4 ro = P.ray_o[my_id], rd = P.ray_d[my_id];
           wo = v3(ro.x, ro.y, ro.z); wd = v3(rd.x, rd.y, rd.z); wb0 = ro.w; wb1 = rd.w;
-          if (P.walk_nr) {
+          if (WALK) {
             // a walk request: the lane starts inside the mesh's tree, as flat_object leaves it there (Tri_Mesh::hit ->
             // BVH<Triangle>::hit with times = dist_bounds / dir.norm()); when the tree is done the object phase finishes
             // Object::hit (world distance) into F.acc, which is the result
@@ -288,15 +295,15 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
     if (!run_leaf && !run_obj) {
       CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_walk);
       if (F.mode == FM_UNWIND) {
-        cast_unwind_step(F, stack);
-        if (P.pops > 1u && F.mode == FM_UNWIND) cast_unwind_step(F, stack);   // (a second pop costs less than another trip)
-      } else if (at_walk) flat_interior(F, stack, S);
-      cast_enter_leaf_objects(F);
+        cast_unwind_step<WALK>(F, stack);
+        if (P.pops > 1u && F.mode == FM_UNWIND) cast_unwind_step<WALK>(F, stack);   // (a second pop costs less than another trip)
+      } else if (at_walk) flat_interior<LdsStack, WALK ? 1 : -1>(F, stack, S);
+      if (!WALK) cast_enter_leaf_objects(F);
       CAST_STAT(CS_T_INTERIOR, __builtin_readcyclecounter() - t0);
     } else if (run_obj) {
       CAST_STAT(CS_OBJECT_TRIPS, 1); CAST_STAT(CS_OBJECT_LANES, n_obj);
       if (at_obj) {
-        if (F.level) flat_exit(F, S, wo, wd, wd, wd, wb0, wb1);   // back from a mesh's tree: finish its Object::hit
+        if (WALK || F.level) flat_exit(F, S, wo, wd, wd, wd, wb0, wb1);   // back from a mesh's tree: finish its Object::hit
         else if (F.obj_i < F.obj_end) flat_object(F, S);          // the next object of the leaf / list
         if (F.mode == FM_OBJECT && F.obj_i >= F.obj_end) { F.ret = F.acc; F.mode = FM_UNWIND; }
       }

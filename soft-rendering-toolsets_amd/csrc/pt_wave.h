@@ -914,6 +914,14 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           };
 #pragma unroll
           for (int r = 0; r < NR; r++) { L[r] = no_hit(); R[r] = no_hit(); }
+          if (pass == 1) {
+            // The probe pass needs no result, only the requests: the sibling counts as unknown for every ray (3 % more
+            // requests than with the visit rule applied to a known sibling), and nothing else of the bottom-up sweep runs
+            // - the batch is swept once, in the complete pass, instead of twice.
+            if (lazy_l) queued(W.l_ref, true, R, false, L);
+            if (lazy_r) queued(W.r_ref, false, L, false, R);
+            continue;
+          }
           if (!lazy_l) eval_child(W.l_ref, W.l_cnt, L, act);
           if (!lazy_r) eval_child(W.r_ref, W.r_cnt, R, act);
           if (lazy_l) queued(W.l_ref, true, R, (lz & 2u) == 0u, L);
