@@ -52,18 +52,38 @@ enum {
 // The first `k` frames of a lane live in LDS, deeper ones in a per-lane column of global memory (`g`, frame i word j at
 // g[((i - k) * 3 + j) * gstride]): with the childless-frame rule of flat_interior a walk rarely gets that deep, and LDS sized
 // for the tree's full depth is what limited the kernel's waves per CU.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // (an explicit LDS pointer: ds_read / ds_write, never FLAT)
 struct LdsStack {
-  uint32_t* w;   // this lane's column: word k of frame i at w[(i * 3 + k) * 64]
+  lds_u32* w;    // this lane's column: word k of frame i at w[(i * 3 + k) * 64]
   uint32_t* g;
   int k;
   uint32_t gstride;
+  // The LDS access is unconditional (clamped index) and the global one sits behind a wave-uniform test: with both behind
+  // per-lane branches the compiler merges them into FLAT loads of a selected address, which wait on both counters.
+  SRT_DEV void load3(int i, uint32_t& w0, uint32_t& w1, uint32_t& w2) const {
+    const bool deep = i >= k;
+    const int il = deep ? 0 : i;
+    w0 = w[(il * 3 + 0) * 64]; w1 = w[(il * 3 + 1) * 64]; w2 = w[(il * 3 + 2) * 64];
+    if (__ballot(deep) != 0ull) {
+      if (deep) {
+        const size_t at = (size_t)(i - k) * 3u * gstride;
+        w0 = g[at]; w1 = g[at + gstride]; w2 = g[at + 2u * (size_t)gstride];
+      }
+    }
+  }
+  SRT_DEV void store3(int i, uint32_t w0, uint32_t w1, uint32_t w2) const {
+    const bool deep = i >= k;
+    if (!deep) { w[(i * 3 + 0) * 64] = w0; w[(i * 3 + 1) * 64] = w1; w[(i * 3 + 2) * 64] = w2; }
+    if (__ballot(deep) != 0ull) {
+      if (deep) {
+        const size_t at = (size_t)(i - k) * 3u * gstride;
+        g[at] = w0; g[at + gstride] = w1; g[at + 2u * (size_t)gstride] = w2;
+      }
+    }
+  }
   SRT_DEV FlatFrame load(int i) const {
     uint32_t w0, w1, w2;
-    if (i < k) { w0 = w[(i * 3 + 0) * 64]; w1 = w[(i * 3 + 1) * 64]; w2 = w[(i * 3 + 2) * 64]; }
-    else {
-      const size_t at = (size_t)(i - k) * 3u * gstride;
-      w0 = g[at]; w1 = g[at + gstride]; w2 = g[at + 2u * (size_t)gstride];
-    }
+    load3(i, w0, w1, w2);
     FlatFrame f;
     f.a = __uint_as_float(w1);
     f.b = w2;
@@ -75,11 +95,7 @@ struct LdsStack {
   SRT_DEV void store(int i, const FlatFrame& f) const {
     const bool near_done = (f.fl & 2u) != 0;
     const uint32_t w0 = near_done ? (((f.fl >> 3) << 2) | 2u | ((f.fl >> 2) & 1u)) : (((uint32_t)f.second << 2) | (f.fl & 1u));
-    if (i < k) { w[(i * 3 + 0) * 64] = w0; w[(i * 3 + 1) * 64] = __float_as_uint(f.a); w[(i * 3 + 2) * 64] = f.b; }
-    else {
-      const size_t at = (size_t)(i - k) * 3u * gstride;
-      g[at] = w0; g[at + gstride] = __float_as_uint(f.a); g[at + 2u * (size_t)gstride] = f.b;
-    }
+    store3(i, w0, __float_as_uint(f.a), f.b);
   }
 };
 
@@ -174,15 +190,32 @@ enum { CS_OUTER = 0, CS_FETCH, CS_INTERIOR_TRIPS, CS_INTERIOR_LANES, CS_LEAF_TRI
 // (flat_pop) - or, with no frame of the current tree left, the end of that tree: a mesh's tree hands over to the object
 // phase (Object::hit is finished there), the top-level tree finishes the ray.
 // (WALK: every lane is inside a mesh's tree, which starts at frame 0.)
-template <bool WALK, typename StackT>
-SRT_DEV void cast_unwind_step(FlatState& F, const StackT& stack) {
-  if (WALK) {
-    if (F.sp != 0) flat_pop(F, stack);
-    else F.mode = FM_OBJECT;
-    return;
-  }
-  if (flat_plain_frame(F)) flat_pop(F, stack);
-  else if (F.level) F.mode = FM_OBJECT;
+// The pop is flat_pop (pt_flat.h) written on the packed frame words: word 0 = payload << 2 | near_done << 1 | flag.
+template <bool WALK>
+SRT_DEV void cast_unwind_step(FlatState& F, const LdsStack& stack) {
+  const bool plain = WALK ? (F.sp != 0) : flat_plain_frame(F);
+  if (plain) {
+    uint32_t w0, w1, w2;
+    stack.load3(F.sp - 1, w0, w1, w2);
+    SRT_PIN_VGPR(w0);                                    // (see flat_pop: the farther child's reference must survive the inlining)
+    const float a = __uint_as_float(w1);
+    if ((w0 & 2u) == 0u) {
+      // back from the nearer child: student/bvh.inl:216 - also visit the farther one iff ...
+      if (a < F.ret.dist || (!F.ret.hit && (w0 & 1u) != 0u)) {
+        stack.store3(F.sp - 1, (F.ret.obj << 2) | 2u | (F.ret.hit ? 1u : 0u), __float_as_uint(F.ret.dist), F.ret.tri);
+        F.cur = (int32_t)w0 >> 2; F.tx = a; F.ty = __uint_as_float(w2);
+        F.mode = FM_NODE;
+      } else F.sp--;
+    } else {
+      // back from the farther child: Trace::min(nearer, farther) - the nearer result wins only when strictly closer
+      const bool saved = left_wins((w0 & 1u) != 0u, a, F.ret.hit, F.ret.dist);
+      F.ret.hit = saved ? true : F.ret.hit;
+      F.ret.dist = saved ? a : F.ret.dist;
+      F.ret.obj = saved ? (w0 >> 2) : F.ret.obj;
+      F.ret.tri = saved ? w2 : F.ret.tri;
+      F.sp--;
+    }
+  } else if (WALK || F.level) F.mode = FM_OBJECT;
   else { F.res0 = F.ret; F.mode = FM_DONE; }
 }
 // A lane that has just arrived at a BVH<Object> leaf: its objects are next.
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
     return;
   }
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-  const LdsStack stack{cast_lds + (size_t)wave * P.lds_frames * 3u * 64u + (uint32_t)lane,
+  const LdsStack stack{(lds_u32*)cast_lds + (size_t)wave * P.lds_frames * 3u * 64u + (uint32_t)lane,
                        P.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x, (int)P.lds_frames, gridDim.x * blockDim.x};
   FlatState F;                                            // F.mode == FM_DONE: the lane is idle
   bool have = false;                                      // the lane holds a finished ray whose result is not written yet
@@ -295,8 +328,8 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
     if (!run_leaf && !run_obj) {
       CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_walk);
       if (F.mode == FM_UNWIND) {
-        cast_unwind_step<WALK>(F, stack);
-        if (P.pops > 1u && F.mode == FM_UNWIND) cast_unwind_step<WALK>(F, stack);   // (a second pop costs less than another trip)
+#pragma nounroll
+        for (uint32_t k = 0; k < P.pops && F.mode == FM_UNWIND; k++) cast_unwind_step<WALK>(F, stack);   // (a second pop costs less than another trip)
       } else if (at_walk) flat_interior<LdsStack, WALK ? 1 : -1>(F, stack, S);
       if (!WALK) cast_enter_leaf_objects(F);
       CAST_STAT(CS_T_INTERIOR, __builtin_readcyclecounter() - t0);
