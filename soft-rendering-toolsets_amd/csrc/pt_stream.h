@@ -52,6 +52,12 @@ enum {
 // The first `k` frames of a lane live in LDS, deeper ones in a per-lane column of global memory (`g`, frame i word j at
 // g[((i - k) * 3 + j) * gstride]): with the childless-frame rule of flat_interior a walk rarely gets that deep, and LDS sized
 // for the tree's full depth is what limited the kernel's waves per CU.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// The streamed forms' queue traffic - rays, list entries, hits, saved path state - passes through memory once per generation:
+// non-temporal accesses, so that it does not push the scene out of L2.
+SRT_DEV void nt_store_ray(float4* plane, size_t i, float x, float y, float z, float w) { __builtin_nontemporal_store(f32x4{x, y, z, w}, reinterpret_cast<f32x4*>(plane) + i); }
+SRT_DEV uint2 nt_load_hit(const uint2* hits, size_t i) { const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hits) + i); return make_uint2(v.x, v.y); }
 typedef __attribute__((address_space(3))) uint32_t lds_u32;   // (an explicit LDS pointer: ds_read / ds_write, never FLAT)
 struct LdsStack {
   lds_u32* w;    // this lane's column: word k of frame i at w[(i * 3 + k) * 64]
@@ -281,7 +287,8 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
         o.x = __float_as_uint(h.hit ? h.dist : 0.0f);
         o.y = h.hit ? ((h.obj << P.obj_shift) | h.tri) : 0xFFFFFFFFu;
         if (WALK) o.y = h.hit ? h.tri : 0xFFFFFFFFu;
-        P.hits[my_id] = o;
+        // (rays, list entries and hits pass through once: non-temporal, so they do not push the tree out of L2)
+        __builtin_nontemporal_store(u32x2_t{o.x, o.y}, reinterpret_cast<u32x2_t*>(P.hits) + my_id);
         have = false;
       }
       if (!exhausted) {                                   // new rays in: one atomic per wave
@@ -291,8 +298,9 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const uint32_t idx = start + rank;
         if (F.mode == FM_DONE && idx < nrays) {
-          my_id = P.ray_id[idx];
-          const float4 ro = P.ray_o[my_id], rd = P.ray_d[my_id];
+          my_id = __builtin_nontemporal_load(P.ray_id + idx);
+          const f32x4 ro = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_o) + my_id);
+          const f32x4 rd = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_d) + my_id);
           wo = v3(ro.x, ro.y, ro.z); wd = v3(rd.x, rd.y, rd.z); wb0 = ro.w; wb1 = rd.w;
           if (WALK) {
             // a walk request: the lane starts inside the mesh's tree, as flat_object leaves it there (Tri_Mesh::hit ->

@@ -365,7 +365,7 @@ SRT_DEV void object_queueN(const DScene& S, uint32_t k, V3 org, const V3* d, con
 #pragma unroll
     for (int r = 0; r < NR; r++) {
       if (need[r]) {
-        const uint2 hv = QP.hits[(size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global];
+        const uint2 hv = nt_load_hit(QP.hits, (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global);
         hit[r] = hv.y != 0xFFFFFFFFu;
         dist[r] = hit[r] ? __uint_as_float(hv.x) : 0.0f;
         tri[r] = hit[r] ? hv.y : 0u;
@@ -405,8 +405,8 @@ SRT_DEV void object_queueN(const DScene& S, uint32_t k, V3 org, const V3* d, con
   for (int r = 0; r < NR; r++) {
     if (need[r]) {
       const size_t pos = (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global;
-      QP.ray_o[pos] = make_float4(oorg.x, oorg.y, oorg.z, ob0[r]);
-      QP.ray_d[pos] = make_float4(od[r].x, od[r].y, od[r].z, ob1[r]);
+      nt_store_ray(QP.ray_o, pos, oorg.x, oorg.y, oorg.z, ob0[r]);
+      nt_store_ray(QP.ray_d, pos, od[r].x, od[r].y, od[r].z, ob1[r]);
       emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
     }
   }
@@ -429,7 +429,6 @@ enum { ST_REFILL = 0, ST_TOPDOWN, ST_LEAVES, ST_COMBINE, ST_POST, ST_SHADE, ST_T
 // persistent sweep kernel keeps these in LDS, [variable][thread]: it needs ~150 VGPRs and runs with 128 (4 waves / SIMD is
 // worth 11 % over 3), so what does not fit goes to scratch, and scratch lines that fall out of L2 were most of the kernel's
 // memory traffic (profiles/README.md); a value parked in LDS costs a ds_read where it is used and no traffic at all.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool IN_LDS> struct ColdU32;
 template <> struct ColdU32<false> {
   uint32_t v;
@@ -570,7 +569,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   // TRAV == 3 (pt_stream.h): this invocation is one generation.  The slot's state comes from HBM, pass 0 of the loop
   // consumes the hits of the batch emitted by the previous generation (step 3 as it stands), pass 1 refills idle slots,
   // appends the next batch's rays to the queue and saves the state.
-#define ST(w) P.state[(size_t)(w) * P.nlanes + lane_global]
+#define ST(w) __builtin_nontemporal_load(P.state + ((size_t)(w) * P.nlanes + lane_global))
+#define ST_SET(w, v) __builtin_nontemporal_store((uint32_t)(v), P.state + ((size_t)(w) * P.nlanes + lane_global))
 // (non-temporal: a record is written once and read once, a sample is written once - they should not push the waves' scratch
 //  lines out of L2 on their way through)
 #define REC_AT(lev, half) (reinterpret_cast<f32x4*>(P.records) + (((size_t)lane_global * kMaxPathDepth + (size_t)(lev)) * 2u + (half)))
@@ -612,31 +612,31 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   }
 
   auto save_state = [&]() {
-    ST(SW_FLAGS) = (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
-                   (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16);
-    ST(SW_EMIT) = emit_mask | (alive ? 0x80000000u : 0u);   // (bit 31: the slot is alive - a generation without requests need not be the last)
+    ST_SET(SW_FLAGS, (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
+                   (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16));
+    ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));   // (bit 31: the slot is alive - a generation without requests need not be the last)
     if (alive) {
-      ST(SW_PX) = PX_; ST(SW_PY) = PY_; ST(SW_PIXEL_SLOT) = pixel_slot;
-      ST(SW_SAMPLES) = samp;
-      ST(SW_PEND0) = pend0;
-      if (NR > 2) ST(SW_PEND1) = pend1;
-      ST(SW_RNG_LO) = (uint32_t)rng.state; ST(SW_RNG_HI) = (uint32_t)(rng.state >> 32);
-      ST(SW_ORG) = __float_as_uint(org.x); ST(SW_ORG + 1) = __float_as_uint(org.y); ST(SW_ORG + 2) = __float_as_uint(org.z);
-      ST(SW_DC) = __float_as_uint(d[C].x); ST(SW_DC + 1) = __float_as_uint(d[C].y); ST(SW_DC + 2) = __float_as_uint(d[C].z);
-      ST(SW_CB0) = __float_as_uint(cb0); ST(SW_CB1) = __float_as_uint(cb1);
-      ST(SW_ATT) = __float_as_uint(att.r); ST(SW_ATT + 1) = __float_as_uint(att.g); ST(SW_ATT + 2) = __float_as_uint(att.b);
-      ST(SW_PDF4) = __float_as_uint(pdf4); ST(SW_PDF_AREA) = __float_as_uint(pdf_area);
+      ST_SET(SW_PX, PX_); ST_SET(SW_PY, PY_); ST_SET(SW_PIXEL_SLOT, pixel_slot);
+      ST_SET(SW_SAMPLES, samp);
+      ST_SET(SW_PEND0, pend0);
+      if (NR > 2) ST_SET(SW_PEND1, pend1);
+      ST_SET(SW_RNG_LO, (uint32_t)rng.state); ST_SET(SW_RNG_HI, (uint32_t)(rng.state >> 32));
+      ST_SET(SW_ORG, __float_as_uint(org.x)); ST_SET(SW_ORG + 1, __float_as_uint(org.y)); ST_SET(SW_ORG + 2, __float_as_uint(org.z));
+      ST_SET(SW_DC, __float_as_uint(d[C].x)); ST_SET(SW_DC + 1, __float_as_uint(d[C].y)); ST_SET(SW_DC + 2, __float_as_uint(d[C].z));
+      ST_SET(SW_CB0, __float_as_uint(cb0)); ST_SET(SW_CB1, __float_as_uint(cb1));
+      ST_SET(SW_ATT, __float_as_uint(att.r)); ST_SET(SW_ATT + 1, __float_as_uint(att.g)); ST_SET(SW_ATT + 2, __float_as_uint(att.b));
+      ST_SET(SW_PDF4, __float_as_uint(pdf4)); ST_SET(SW_PDF_AREA, __float_as_uint(pdf_area));
       if constexpr (DL || TRAV == 4) {
-        ST(SW_D0) = __float_as_uint(d[0].x); ST(SW_D0 + 1) = __float_as_uint(d[0].y); ST(SW_D0 + 2) = __float_as_uint(d[0].z);
-        if (NR > 2) { ST(SW_D1) = __float_as_uint(d[1].x); ST(SW_D1 + 1) = __float_as_uint(d[1].y); ST(SW_D1 + 2) = __float_as_uint(d[1].z); }
+        ST_SET(SW_D0, __float_as_uint(d[0].x)); ST_SET(SW_D0 + 1, __float_as_uint(d[0].y)); ST_SET(SW_D0 + 2, __float_as_uint(d[0].z));
+        if (NR > 2) { ST_SET(SW_D1, __float_as_uint(d[1].x)); ST_SET(SW_D1 + 1, __float_as_uint(d[1].y)); ST_SET(SW_D1 + 2, __float_as_uint(d[1].z)); }
       }
       if constexpr (DL) {
-        ST(SW_LIGHT_I) = light_i; ST(SW_HELD) = held_chit;
-        ST(SW_PL) = __float_as_uint(pl.r); ST(SW_PL + 1) = __float_as_uint(pl.g); ST(SW_PL + 2) = __float_as_uint(pl.b);
-        ST(SW_DA) = __float_as_uint(dA_keep.r); ST(SW_DA + 1) = __float_as_uint(dA_keep.g); ST(SW_DA + 2) = __float_as_uint(dA_keep.b);
-        ST(SW_D6) = __float_as_uint(d6_keep.r); ST(SW_D6 + 1) = __float_as_uint(d6_keep.g); ST(SW_D6 + 2) = __float_as_uint(d6_keep.b);
-        ST(SW_DCK) = __float_as_uint(dC_keep.x); ST(SW_DCK + 1) = __float_as_uint(dC_keep.y); ST(SW_DCK + 2) = __float_as_uint(dC_keep.z);
-        ST(SW_SB1) = __float_as_uint(sb1[0]); ST(SW_SB1 + 1) = __float_as_uint(sb1[1]); ST(SW_SB1 + 2) = __float_as_uint(sb1[2]);
+        ST_SET(SW_LIGHT_I, light_i); ST_SET(SW_HELD, held_chit);
+        ST_SET(SW_PL, __float_as_uint(pl.r)); ST_SET(SW_PL + 1, __float_as_uint(pl.g)); ST_SET(SW_PL + 2, __float_as_uint(pl.b));
+        ST_SET(SW_DA, __float_as_uint(dA_keep.r)); ST_SET(SW_DA + 1, __float_as_uint(dA_keep.g)); ST_SET(SW_DA + 2, __float_as_uint(dA_keep.b));
+        ST_SET(SW_D6, __float_as_uint(d6_keep.r)); ST_SET(SW_D6 + 1, __float_as_uint(d6_keep.g)); ST_SET(SW_D6 + 2, __float_as_uint(d6_keep.b));
+        ST_SET(SW_DCK, __float_as_uint(dC_keep.x)); ST_SET(SW_DCK + 1, __float_as_uint(dC_keep.y)); ST_SET(SW_DCK + 2, __float_as_uint(dC_keep.z));
+        ST_SET(SW_SB1, __float_as_uint(sb1[0])); ST_SET(SW_SB1 + 1, __float_as_uint(sb1[1])); ST_SET(SW_SB1 + 2, __float_as_uint(sb1[2]));
       }
     }
   };
@@ -743,8 +743,8 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         for (int r = 0; r < NR; r++) {
           if (eact[r]) {
             const size_t i = (size_t)r * P.nlanes + lane_global;
-            P.ray_o[i] = make_float4(org.x, org.y, org.z, cb0);
-            P.ray_d[i] = make_float4(d[r].x, d[r].y, d[r].z, eb1[r]);
+            nt_store_ray(P.ray_o, i, org.x, org.y, org.z, cb0);
+            nt_store_ray(P.ray_d, i, d[r].x, d[r].y, d[r].z, eb1[r]);
             emit_mask |= 1u << r;
           }
         }
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
       for (int r = 0; r < NR; r++) {
         res[r] = no_hit();
         if (act[r]) {
-          const uint2 hv = P.hits[(size_t)r * P.nlanes + lane_global];
+          const uint2 hv = nt_load_hit(P.hits, (size_t)r * P.nlanes + lane_global);
           res[r] = unpack_ret(__uint_as_float(hv.x), hv.y, oshift);
         }
       }
@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
 
 #undef SLOT
 #undef ST
+#undef ST_SET
 #undef REC_AT
 #undef REC_STORE
 #undef REC_LOAD

@@ -4,4 +4,3 @@ timeout -k 10 500 python3 -m pytest tests/test_pt_gpu.py -x -q -m gpu > gpurun_o
 tail -2 gpurun_out/t_sk.log
 export SRT_WARM_FULL=1 SRT_STREAM_TIMES=1
 python3 tools/pt_scene_bench.py blob7 1024 64 7,6 2>&1 | grep -E "mode |per-kernel"
-for p in 1 3; do echo "pops $p"; SRT_CAST_POPS=$p python3 tools/pt_scene_bench.py blob7 1024 64 7 2>&1 | grep -E "mode |per-kernel"; done
