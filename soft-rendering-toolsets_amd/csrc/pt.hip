@@ -734,6 +734,10 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       if (C.fetch_min < 1u) C.fetch_min = 1u;
       C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 8u;
       C.object_min = getenv("SRT_CAST_OBJECT") ? (uint32_t)atoi(getenv("SRT_CAST_OBJECT")) : 16u;
+      C.own_share = getenv("SRT_CAST_OWN") ? (uint32_t)atoi(getenv("SRT_CAST_OWN")) : 128u;
+      C.grab = getenv("SRT_CAST_GRAB") ? (uint32_t)atoi(getenv("SRT_CAST_GRAB")) : 32u;
+      if (C.grab < 1u) C.grab = 1u;
+      if (C.own_share > 256u) C.own_share = 256u;
       C.pops = getenv("SRT_CAST_POPS") ? (uint32_t)atoi(getenv("SRT_CAST_POPS")) : 2u;
       if (C.leaf_min < 1u) C.leaf_min = 1u;
       if (C.object_min < 1u) C.object_min = 1u;

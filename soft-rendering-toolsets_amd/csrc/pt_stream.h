@@ -127,6 +127,8 @@ struct CastParams {
   uint32_t interior_min;     // (unused by the phase scheduler; kept for experiments)
   uint32_t leaf_min;         // lanes waiting at BVH<Triangle> leaves that make the wave run the leaf phase
   uint32_t object_min;       // lanes waiting at objects that make the wave run the object phase
+  uint32_t grab;             // entries a wave takes from the pool per atomic
+  uint32_t own_share;        // 0..256: this many 256ths of the list are dealt out to the waves in advance, the rest is a common pool
   uint32_t pops;             // pops a lane may take per walk trip (1 or 2)
   uint32_t obj_shift;
   unsigned long long* stats;   // STATS build only: CS_* sums over all waves
@@ -258,6 +260,12 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   const LdsStack stack{(lds_u32*)cast_lds + (size_t)wave * P.lds_frames * 3u * 64u + (uint32_t)lane,
                        P.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x, (int)P.lds_frames, gridDim.x * blockDim.x};
+  // this wave's own run of the list and the start of the common pool (P.own_share / 256 of the list is dealt out)
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave_global = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+  const uint32_t own_n = (uint32_t)(((unsigned long long)nrays * P.own_share) >> 8) / nwaves;
+  uint32_t own_next = wave_global * own_n, own_end = own_next + own_n;
+  const uint32_t pool_base = nwaves * own_n;
+  bool pool_done = false;
   FlatState F;                                            // F.mode == FM_DONE: the lane is idle
   bool have = false;                                      // the lane holds a finished ray whose result is not written yet
   bool exhausted = false;                                 // the queue has nothing left for this wave
@@ -293,11 +301,26 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
       }
       if (!exhausted) {                                   // new rays in: one atomic per wave
         uint32_t start = 0;
-        if (lane == 0) start = atomicAdd(P.head, nidle);
-        start = (uint32_t)__shfl((int)start, 0);
+        // Most of the list is dealt out in advance, a contiguous run per wave that the wave walks through by itself; only
+        // the last part is a common pool behind one counter.  (Every fetch an atomic on that one word: ~31 000 of them per
+        // generation at the ~90 per microsecond a single address takes was a good part of this kernel's time;
+        // the pool is taken P.grab entries at a time, into the wave's own run.)
+        if (own_next >= own_end && !pool_done) {
+          if (lane == 0) start = atomicAdd(P.head, P.grab);
+          start = pool_base + (uint32_t)__shfl((int)start, 0);
+          if (start >= nrays) pool_done = true;
+          else { own_next = start; own_end = start + P.grab < nrays ? start + P.grab : nrays; }
+        }
+        uint32_t take = 0;
+        if (own_next < own_end) {
+          take = own_end - own_next < nidle ? own_end - own_next : nidle;
+          start = own_next;
+          own_next += take;
+        }
+        exhausted = pool_done && own_next >= own_end;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const uint32_t idx = start + rank;
-        if (F.mode == FM_DONE && idx < nrays) {
+        if (F.mode == FM_DONE && rank < take && idx < nrays) {
           my_id = __builtin_nontemporal_load(P.ray_id + idx);
           const f32x4 ro = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_o) + my_id);
           const f32x4 rd = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_d) + my_id);
@@ -325,7 +348,6 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
           }
           have = true;
         }
-        if (start + nidle >= nrays) exhausted = true;
       }
       CAST_STAT(CS_T_FETCH, __builtin_readcyclecounter() - t0);
       if (__ballot(F.mode != FM_DONE) == 0ull && exhausted) break;
