@@ -732,7 +732,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 8u;
       C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
       if (C.fetch_min < 1u) C.fetch_min = 1u;
-      C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 8u;
+      C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 12u;
       C.object_min = getenv("SRT_CAST_OBJECT") ? (uint32_t)atoi(getenv("SRT_CAST_OBJECT")) : 16u;
       C.own_share = getenv("SRT_CAST_OWN") ? (uint32_t)atoi(getenv("SRT_CAST_OWN")) : 128u;
       C.grab = getenv("SRT_CAST_GRAB") ? (uint32_t)atoi(getenv("SRT_CAST_GRAB")) : 32u;

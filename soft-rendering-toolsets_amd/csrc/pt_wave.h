@@ -463,7 +463,7 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #define SRT_WAVE_OCC3T 4
 #endif
 #ifndef SRT_STREAM_OCC
-#define SRT_STREAM_OCC 3
+#define SRT_STREAM_OCC 4
 #endif
 __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC))) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
