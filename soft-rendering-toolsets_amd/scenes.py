@@ -172,6 +172,17 @@ def cornell_with_mesh(n_subdiv: int = 7, material: str = "glass") -> dict:
     return s
 
 
+def cornell_with_asset(positions, triangles, T_rows, material: str = "glass", name: str = "asset") -> dict:
+    """The Cornell box with an indexed triangle mesh (positions N x 3, triangles M x 3) in place of the glass sphere, posed by
+    the row-major 4 x 4 `T_rows` (rotation / scale / translation: Object::hit's transform path), flat shaded."""
+    s = cornell_box("cbox")
+    p, n, i = _flat_mesh_fast(np.asarray(positions, F), np.asarray(triangles))
+    mat = 6 if material == "glass" else 5
+    s["objects"][6] = {"kind": "mesh", "pos": p, "nrm": n, "idx": i, "T": _colmajor(T_rows), "material": mat, "is_light": False}
+    s["name"] = f"cbox+{name}{len(triangles)}"
+    return s
+
+
 def _flat_mesh_fast(positions, triangles):
     """Vectorised flat_mesh (same float32 operation order)."""
     P = np.asarray(positions, F)

@@ -136,6 +136,13 @@ def pt_scene(name):
         # BASELINE configs[4] stand-in at size: Cornell walls + light + mirror sphere + a 131 072-triangle glass mesh
         # (the Stanford dragon is a missing large blob of the reference checkout; DESIGN.md names the substitute)
         return scenes.cornell_with_mesh(7, "glass")
+    if name == "cbox_beast_glass":
+        # the reference's own largest mesh asset (S/media/beast.dae, 64 618 triangles; geometry extracted by
+        # tests/golden/make_beast_mesh.py) as a glass object in the Cornell box, Z-up -> Y-up, turned 30 degrees, scaled 0.22
+        import os
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mesh_beast.npz"))
+        T = [0.19052559, -0.11, 0, 0.18, 0, 0, 0.22, 0.016, -0.11, -0.19052559, 0, 0.2, 0, 0, 0, 1]
+        return scenes.cornell_with_asset(g["positions"], g["triangles"], T, "glass", "beast")
     if name == "cbox_refract":
         s = scenes.cornell_box("cbox")
         s["materials"][6] = {"type": scenes.REFRACT, "a": np.ones(3, np.float32), "b": np.zeros(3, np.float32), "ior": 1.5}

@@ -45,6 +45,8 @@ CASES = [
     # BASELINE configs[4] at size: 131 072-triangle glass mesh in the box, 1024 x 1024; the BVH<Triangle> (80 127 nodes) is
     # stored as SHA-256 digests of its arrays, the rest as for the other cases
     ("cbox_blob131072_glass", 1024, 1024, 8, True, 4096, (24, 24, 4)),
+    # the reference's own largest mesh asset (media/beast.dae, 64 618 triangles) as the glass object, posed by a rotation + scale
+    ("cbox_beast_glass", 512, 512, 8, True, 4096, (24, 24, 4)),
 ]
 BIG_BLAS = 4096   # node arrays longer than this are stored as digests
 SEED = 20260331
