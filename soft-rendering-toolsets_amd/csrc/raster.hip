@@ -157,6 +157,12 @@ __device__ __forceinline__ uint32_t bins_of_super(const RasterParams& P, uint32_
   return bw * bh;
 }
 
+#ifndef SRT_BIN_K1
+#define SRT_BIN_K1 24
+#endif
+#ifndef SRT_BIN_K2
+#define SRT_BIN_K2 8
+#endif
 template <int LEVEL>
 __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const int4* __restrict__ bbox, const uint32_t* __restrict__ in_lists,
                                                          const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_lists,
@@ -195,41 +201,56 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
     out = out_lists + s_base;
     if (threadIdx.x == 0) offs[bin] = s_base;
   }
-  // K candidates per thread and step (candidate j * blockDim + thread of the step: coalesced loads; a step's order is
-  // j-major, the block-wide prefix below follows it): the serial chain of a block - load, ballot, barrier, scatter - is what
-  // a frame waits for at level 1, where <= 64 blocks walk the whole stream: 8192 candidates per step instead of 1024
-  constexpr int K = (LEVEL == 1) ? 8 : 1;
-  __shared__ uint32_t wave_cnt_k[2][K][16];
+  // K candidates per thread and step, candidate j * blockDim + thread of the step (coalesced loads; a thread's K loads are
+  // independent and in flight together).  A step's order is (j, wave, lane): the hits of (j, wave) are a ballot mask kept in
+  // LDS, one wave turns the K x 16 mask populations into exclusive offsets, and a thread with a hit needs two LDS reads to
+  // know where it goes.  (The first two-level version had every thread add up sixteen wave counts per candidate and took
+  // three steps for cfg2's stream: 17.6 us at level 1; K consecutive candidates per thread - 64 lines per load - cost the same.)
+  constexpr int K = (LEVEL == 1) ? SRT_BIN_K1 : SRT_BIN_K2;
+  constexpr int NM = K * 16;                            // masks per step
+  __shared__ unsigned long long s_mask[NM];
+  __shared__ uint32_t s_pref[NM + 1];
   uint32_t total = 0;
-  int flip = 0;
-  for (uint32_t base = 0; base < ncand; base += blockDim.x * K, flip ^= 1) {
-    uint32_t idx[K];
-    bool ov[K];
+  for (uint32_t base = 0; base < ncand; base += blockDim.x * K) {
+    uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < K; j++) {
       const uint32_t k = base + (uint32_t)j * blockDim.x + threadIdx.x;
-      idx[j] = 0;
       int4 bb = make_int4(1, 1, 0, 0);
-      if (k < ncand) { idx[j] = (LEVEL == 1) ? k : in[k]; bb = bbox[idx[j]]; }
-      ov[j] = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+      if (k < ncand) bb = bbox[(LEVEL == 1) ? k : in[k]];
+      const bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+      const unsigned long long m = __ballot(ov);
+      if (lane == 0) s_mask[j * 16 + wave] = (wave < nwaves) ? m : 0ull;
+      mine |= (ov ? 1u : 0u) << j;
     }
-    uint32_t lane_before[K];
+    if (nwaves < 16 && threadIdx.x < 64)                 // (blocks of fewer than 16 waves: the other columns count nothing)
+      for (int e = lane; e < NM; e += 64) if ((e & 15) >= nwaves) s_mask[e] = 0ull;
+    __syncthreads();
+    if (wave == 0) {
+      // exclusive offsets of the NM masks in (j, wave) order: NM / 64 consecutive entries per lane, then a wave scan
+      constexpr int PER = (NM + 63) / 64;
+      uint32_t cnt[PER], sum = 0;
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      const unsigned long long m = __ballot(ov[j]);
-      lane_before[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_cnt_k[flip][j][wave] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();                                   // (the counts of the next step go to the other buffer: one barrier per step)
-    uint32_t at = total;
+      for (int e = 0; e < PER; e++) { const int at = lane * PER + e; cnt[e] = at < NM ? (uint32_t)__popcll(s_mask[at]) : 0u; sum += cnt[e]; }
+      uint32_t incl = sum;
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      uint32_t before = 0, all = 0;
-      for (int w = 0; w < nwaves; w++) { const uint32_t c = wave_cnt_k[flip][j][w]; all += c; before += (w < wave) ? c : 0u; }
-      if (ov[j]) out[at + before + lane_before[j]] = idx[j];
-      at += all;
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += t; }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (int e = 0; e < PER; e++) { const int at = lane * PER + e; if (at < NM) s_pref[at] = run; run += cnt[e]; }
+      if (lane == 63) s_pref[NM] = incl;
     }
-    total = at;
+    __syncthreads();
+    uint32_t m = mine;
+    while (m) {
+      const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
+      m &= m - 1u;
+      const uint32_t k = base + j * blockDim.x + threadIdx.x;
+      const unsigned long long wm = s_mask[j * 16 + wave];
+      out[total + s_pref[j * 16 + wave] + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = (LEVEL == 1) ? k : in[k];
+    }
+    total += s_pref[NM];
+    __syncthreads();                                     // (the next step rewrites the masks)
   }
   if (threadIdx.x == 0) out_counts[blockIdx.x] = total;
 }
