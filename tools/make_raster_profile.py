@@ -41,7 +41,7 @@ def main():
     with open(stats, newline="") as fh:
         for row in csv.DictReader(fh):
             if "raster_" in row["Name"]:
-                kernels[row["Name"].split("(")[0][-40:]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
+                kernels[row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
     tiles, bins = {}, {}
     for sub in ("a", "b"):
         path = find(out, sub, "counter_collection.csv")
