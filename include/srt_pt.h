@@ -135,6 +135,11 @@ int srt_pt_set_env_map(srt_pt* pt, uint32_t width, uint32_t height, const float*
 /* Builds every BVH<Triangle> (leaf size 4) and the BVH<Object> (leaf size 1) exactly as the reference
  * does — or the List<> forms when use_bvh == 0 — flattens them and uploads the scene. */
 int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
+/* Where srt_pt_scene_commit runs BVH<Primitive>::build (student/bvh.inl:35-163): device != 0 (default) builds primitive sets of at
+ * least min_primitives (default 16384) on the GPU, smaller ones and device == 0 on the host.  Both produce the reference's node
+ * arrays and primitive order bit for bit (the candidate planes' std::partition sequence included); SRT_BVH_BUILDER=host in the
+ * environment forces the host build. */
+int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives);
 
 int srt_pt_set_camera(srt_pt* pt, const float iview[16], float vert_fov_deg, float aspect_ratio);
 int srt_pt_set_params(srt_pt* pt, uint32_t width, uint32_t height, uint32_t max_depth);

@@ -338,6 +338,7 @@ struct srt_pt {
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
   const void* cast_kern = nullptr; uint32_t cast_lds_frames = 0;                                 // traversal frames per lane kept in LDS (the deeper ones: d_cast_spill)
   int cast_blocks = 0, cast_threads = 0; size_t cast_lds = 0; uint32_t cast_depth = 0;   // pt_cast_kernel's launch shape (0: not derived yet)
+  int bvh_builder = 1; uint32_t bvh_device_min = 16384;         // srt_pt_set_bvh_builder: device build for sets of >= this many primitives
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
@@ -972,7 +973,13 @@ int srt_pt_set_env_map(srt_pt* pt, uint32_t width, uint32_t height, const float*
 
 int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_scene_commit: NULL context");
+  // BVH<Triangle> builds of big meshes run on the device (pt_bvh_device.hip: identical arrays); srt_pt_set_bvh_builder
+  const char* be = getenv("SRT_BVH_BUILDER");
+  const int bmode = be ? (strcmp(be, "host") == 0 ? 0 : 1) : pt->bvh_builder;
+  if (pt->device >= 0 && bmode != 0) { SRT_HIP(hipSetDevice(pt->device)); set_device_bvh_builder(build_bvh_device, pt->bvh_device_min); }
+  else set_device_bvh_builder(nullptr, 0);
   const std::string err = build_scene(pt->inputs, pt->materials, use_bvh != 0, &pt->built);
+  set_device_bvh_builder(nullptr, 0);
   if (!err.empty()) return srt::fail(SRT_ERR_UNSUPPORTED, "%s", err.c_str());
   pt->built.flat.delta_lights = pt->delta_lights;
   const FlatScene& F = pt->built.flat;
@@ -992,6 +999,13 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
   }
   pt->committed = true;
   pt->cast_blocks = 0;                                    // the ray-cast kernel's stack depth follows the scene
+  return SRT_OK;
+}
+
+int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_bvh_builder: NULL context");
+  pt->bvh_builder = device ? 1 : 0;
+  pt->bvh_device_min = min_primitives;
   return SRT_OK;
 }
 

@@ -72,8 +72,14 @@ uint32_t partition_by_center(std::vector<uint32_t>& prim, const std::vector<Box>
 
 // BVH<Primitive>::build (student/bvh.inl:35-163): level order; per axis up to nine candidate planes
 // min + k*interval (float accumulation), SAH cost, axis chosen by exact float equality with the minimum.
+thread_local DeviceBvhBuilder g_device_builder = nullptr;
+thread_local uint32_t g_device_min = 0;
+
 bool build_bvh(const std::vector<Box>& boxes, uint32_t max_leaf, HostBVH* out) {
   const uint32_t n = (uint32_t)boxes.size();
+  static_assert(sizeof(Box) == 6 * sizeof(float), "Box is six floats");
+  if (g_device_builder && n >= g_device_min && n > max_leaf && g_device_builder(&boxes[0].mn[0], n, max_leaf, out)) return true;
+  // (a device build that fails - no termination, or no memory - falls through: the host build gives the verdict)
   out->nodes.clear();
   out->prim.resize(n);
   for (uint32_t i = 0; i < n; i++) out->prim[i] = i;
@@ -125,6 +131,10 @@ bool build_bvh(const std::vector<Box>& boxes, uint32_t max_leaf, HostBVH* out) {
   }
   return true;
 }
+
+}  // namespace
+void set_device_bvh_builder(DeviceBvhBuilder fn, uint32_t min_prims) { g_device_builder = fn; g_device_min = min_prims; }
+namespace {
 
 // Interior-node nesting of the tree.  Children are allocated after their parent (level order, student/bvh.inl:144-145),
 // so one backward pass over the node array does it - no recursion, however skewed the tree.

@@ -144,6 +144,13 @@ struct BuiltScene {
   std::vector<ObjectInput> inputs;
 };
 
+// BVH<Primitive>::build for large primitive sets on the device (pt_bvh_device.hip; same arrays as the host build, bit for
+// bit).  The hook keeps pt_scene.cpp free of HIP: build_scene uses `fn` for sets of at least `min_prims` primitives when one
+// is installed (thread-local: a context installs its choice around its own build_scene call).
+typedef bool (*DeviceBvhBuilder)(const float* boxes6, uint32_t n, uint32_t max_leaf, HostBVH* out);
+void set_device_bvh_builder(DeviceBvhBuilder fn, uint32_t min_prims);
+bool build_bvh_device(const float* boxes6, uint32_t n, uint32_t max_leaf, HostBVH* out);
+
 Mat4 mat_identity();
 Mat4 mat_inverse(const Mat4& m);   // Mat4::inverse, same term order (lib/mat4.h:296-343)
 Mat4 mat_mul(const Mat4& self, const Mat4& m);  // self * m  (lib/mat4.h:110-121)

@@ -732,3 +732,37 @@ def test_epochs_on_two_streams_overlap_safely(srt):
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     pt.close()
+
+
+@pytest.mark.parametrize("scene_name,min_prims", [("cbox_blob512_glass", 1), ("cbox_blob2048_mirror", 1), ("cbox_beast_glass", 16384),
+                                                  ("cbox_blob131072_glass", 16384)])
+def test_device_bvh_build_equals_host_build(srt, scene_name, min_prims):
+    """BVH::build on the GPU (csrc/pt_bvh_device.hip): node boxes, links and primitive order of every tree - the BVH<Object> too
+    when min_prims = 1 - equal the host build's bit for bit (the host build equals the reference's: tests/test_pt_host.py and
+    the goldens' node arrays), and scene.hit agrees with the oracle through the device-built trees."""
+    import time
+    scene = pt_scene(scene_name)
+    built = []
+    for device in (False, True):
+        pt = srt.Pathtracer(0)
+        pt.set_params(64, 64, 1, 8, True)
+        pt.set_bvh_builder(device, min_prims)
+        t0 = time.perf_counter()
+        pt.build_scene(scene)
+        dt = time.perf_counter() - t0
+        pt.set_camera(scene["camera"])
+        trees = [pt.dump_bvh(-1)]
+        for slot in range(len(scene["objects"])):          # (slots of BVH<Object> order; spheres have no tree)
+            try:
+                trees.append(pt.dump_bvh(slot))
+            except Exception:
+                pass
+        built.append((pt, trees, dt))
+    (pt_h, trees_h, dt_h), (pt_d, trees_d, dt_d) = built
+    print(f"{scene_name}: build_scene host {dt_h * 1e3:.1f} ms, device {dt_d * 1e3:.1f} ms")
+    assert len(trees_h) == len(trees_d)
+    for (bh, lh, oh), (bd, ld, od) in zip(trees_h, trees_d):
+        assert bits_equal(bh, bd) and np.array_equal(lh, ld) and np.array_equal(oh, od)
+    org, d, b = random_rays(91, 1024)
+    assert bits_equal(pt_h.hit(org, d, b), pt_d.hit(org, d, b))
+    pt_h.close(); pt_d.close()
