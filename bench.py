@@ -472,8 +472,8 @@ def main():
     # accumulate is order dependent, so it waits for the previous step's accumulate through an event.
     # The streamed forms (cfg5) gain as well: one epoch's generations leave gaps at every kernel boundary that the other
     # epoch's kernels fill (359.8 -> 341.8 ms per step, same image).
-    nstreams = 1 if (rehearse or args.no_overlap) else 2
-    streams = [torch.cuda.current_stream()] if nstreams == 1 else [torch.cuda.Stream(device=dev) for _ in range(2)]
+    nstreams = 1 if (rehearse or args.no_overlap) else int(os.environ.get("SRT_BENCH_STREAMS", "2"))
+    streams = [torch.cuda.current_stream()] if nstreams == 1 else [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     tiles = [torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev) for _ in range(nstreams)]
     gathered = [torch.zeros(world * per_rank * fpt, dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
                 for _ in range(nstreams)]
