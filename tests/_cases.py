@@ -235,6 +235,15 @@ def pt_scene(name):
             s["objects"] = [o for o in s["objects"] if not (o["kind"] == "mesh" and o["is_light"])]
         s["env"] = {"type": 1 if name == "cbox_envsphere" else 2, "radiance": np.array([0.7, 0.8, 1.0], np.float32)}
         return s
+    if name in ("lone_blob_env", "lone_blob_env_lambertian"):
+        # ONE object, a 512-triangle mesh with a real BVH<Triangle>, under a uniform sphere light: the BVH<Object> root is a
+        # leaf (no interior node to sweep), every ray either enters the mesh's tree or leaves into the environment
+        s = scenes.cornell_with_mesh(3, "glass")
+        s["objects"] = [s["objects"][6]]
+        if name.endswith("lambertian"):
+            s["objects"][0] = dict(s["objects"][0], material=2)
+        s["env"] = {"type": 1, "radiance": np.array([0.7, 0.8, 1.0], np.float32)}
+        return s
     if name == "cbox_nolight":
         s = scenes.cornell_box("cbox_lambertian")
         s["objects"] = s["objects"][:-1]   # no area light: sample_area_lights returns the zero vector -> NaN rays

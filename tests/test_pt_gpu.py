@@ -766,3 +766,21 @@ def test_device_bvh_build_equals_host_build(srt, scene_name, min_prims):
     org, d, b = random_rays(91, 1024)
     assert bits_equal(pt_h.hit(org, d, b), pt_d.hit(org, d, b))
     pt_h.close(); pt_d.close()
+
+
+@pytest.mark.parametrize("name", ["lone_blob_env", "lone_blob_env_lambertian"])
+def test_single_object_scene_every_kernel(srt, name):
+    """A scene of one mesh with a real BVH<Triangle> (BVH<Object> root = leaf: the sweeps have no interior node, the streamed
+    sweeps queue the mesh from the object fold) under an environment light: every kernel form against the oracle."""
+    scene = pt_scene(name)
+    w, h, spp = 48, 40, 5
+    want = H.OraclePT(scene, w, h, 6, True).epoch(3, 1, spp)
+    pt = make_pt(srt, scene, w, h, 6, True)
+    pt.set_params(w, h, spp, 6, True)
+    forms = {}
+    for mode in (0, 1, 2, 4, 6, 7):
+        pt.set_kernel(mode)
+        forms[mode] = pt.kernel_form()
+        assert bits_equal(pt.render_epoch(3, 1, spp), want), f"kernel mode {mode} (form {forms[mode]}) differs from the oracle"
+    assert forms[7] == 4 and forms[6] == 3, forms
+    pt.close()
