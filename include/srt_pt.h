@@ -7,7 +7,7 @@
  *   srt_pt_scene_begin / add_material / add_mesh / add_sphere / scene_commit
  *                          <- Pathtracer::build_scene            rays/pathtracer.cpp:66-176
  *                             (Object ctor rays/object.h:18-34, Tri_Mesh::build student/tri_mesh.cpp:145-170,
- *                              BVH<>::build student/bvh.inl:35-163 — host side, structure-identical)
+ *                              BVH<>::build student/bvh.inl:35-163 — host or device, structure-identical)
  *   srt_pt_set_camera      <- `camera = cam` in begin_render     rays/pathtracer.cpp:267 (Camera: util/camera.h)
  *   srt_pt_set_params      <- Pathtracer::set_params             rays/pathtracer.cpp:182-189
  *   srt_pt_render_epoch    <- Pathtracer::do_trace(samples)      rays/pathtracer.cpp:209-231, i.e. for every pixel
@@ -142,6 +142,8 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
 int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives);
 
 int srt_pt_set_camera(srt_pt* pt, const float iview[16], float vert_fov_deg, float aspect_ratio);
+/* Image size and Pathtracer::max_depth.  Limits (SRT_ERR_UNSUPPORTED beyond): width, height <= 65535, width * height < 2^31,
+ * max_depth <= 16. */
 int srt_pt_set_params(srt_pt* pt, uint32_t width, uint32_t height, uint32_t max_depth);
 
 /* ---- image-tile sharding (one process per GPU) ---------------------------------------------------
