@@ -140,6 +140,10 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
  * arrays and primitive order bit for bit (the candidate planes' std::partition sequence included); SRT_BVH_BUILDER=host in the
  * environment forces the host build. */
 int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives);
+/* The streamed forms (kernel modes 6 / 7, what auto takes for scenes with a real BVH<Triangle> or many objects) keep this many
+ * paths in flight per launch (rounded up to 256; 0 = the default, 2 Mi; ~1 KB of device memory per slot).  The image does not
+ * depend on it. */
+int srt_pt_set_stream_slots(srt_pt* pt, uint32_t slots);
 
 int srt_pt_set_camera(srt_pt* pt, const float iview[16], float vert_fov_deg, float aspect_ratio);
 /* Image size and Pathtracer::max_depth.  Limits (SRT_ERR_UNSUPPORTED beyond): width, height <= 65535, width * height < 2^31,

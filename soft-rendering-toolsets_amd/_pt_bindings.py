@@ -40,6 +40,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_add_sphere.argtypes = [c_void_p, c_float, c_void_p, c_uint32]
     lib.srt_pt_scene_commit.argtypes = [c_void_p, c_int]
     lib.srt_pt_set_bvh_builder.argtypes = [c_void_p, c_int, c_uint32]
+    lib.srt_pt_set_stream_slots.argtypes = [c_void_p, c_uint32]
     lib.srt_pt_set_camera.argtypes = [c_void_p, c_void_p, c_float, c_float]
     lib.srt_pt_set_params.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32]
     lib.srt_pt_set_tiling.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]
@@ -245,6 +246,10 @@ class Pathtracer:
 
     def accumulate_device(self, stream: int, d_acc: int, d_epoch: int, nfloats: int, k: int) -> None:
         self._check(self._lib, self._lib.srt_pt_accumulate_device(self._ctx, c_void_p(stream), c_void_p(d_acc), c_void_p(d_epoch), nfloats, k))
+
+    def set_stream_slots(self, slots: int) -> None:
+        """Paths in flight per launch of the streamed forms (0 = default); the image does not depend on it."""
+        self._check(self._lib, self._lib.srt_pt_set_stream_slots(self._ctx, int(slots)))
 
     def set_bvh_builder(self, device: bool, min_primitives: int = 16384) -> None:
         """Where build_scene runs BVH::build: on the GPU for primitive sets of at least `min_primitives`, else on the host."""

@@ -1002,6 +1002,12 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
   return SRT_OK;
 }
 
+int srt_pt_set_stream_slots(srt_pt* pt, uint32_t slots) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_stream_slots: NULL context");
+  pt->stream_slots = slots;
+  return SRT_OK;
+}
+
 int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_bvh_builder: NULL context");
   pt->bvh_builder = device ? 1 : 0;

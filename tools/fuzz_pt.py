@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the path-tracer kernels: seeded random scenes (tests/_cases.py:random_pt_scene), epoch image of
-every kernel (wave kernel, wave kernel with dead-ray elision, lane per sample, lane per pixel, flattened walk) against
-the CPU oracle, bit for bit, plus equal ray counts.  usage: fuzz_pt.py [first_seed] [count]"""
+every kernel (auto, wave kernel, wave kernel with dead-ray elision, lane per sample, lane per pixel, flattened walk, the
+streamed forms with a small slot population on every third seed) against the CPU oracle, bit for bit, plus equal ray counts;
+odd seeds build every BVH on the device.  usage: fuzz_pt.py [first_seed] [count]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -32,9 +33,14 @@ for seed in range(first, first + count):
             print(f"seed {seed}: non-terminating reference BVH build, refused by oracle and product", flush=True)
         pt.close()
         continue
+    if seed & 1:
+        pt.set_bvh_builder(True, 1)                            # every tree (the BVH<Object> too) from the device build
+    if seed % 3 == 0:
+        pt.set_stream_slots(256 * (1 + seed % 5))              # a small population: refills, many generations
     pt.build_scene(scene); pt.set_camera(scene["camera"])
     rays = {}
-    for label, mode, elide in (("wave", 2, False), ("wave+elide", 2, True), ("unit", 4, False), ("unit+elide", 4, True), ("pixel", 1, False), ("flat", 5, False)):
+    for label, mode, elide in (("auto", 0, False), ("wave", 2, False), ("wave+elide", 2, True), ("unit", 4, False), ("unit+elide", 4, True), ("pixel", 1, False),
+                               ("flat", 5, False), ("stream", 6, False), ("stream+elide", 6, True), ("stream-sweeps", 7, False), ("stream-sweeps+elide", 7, True)):
         try:
             pt.set_kernel(mode)
         except srt_amd.SrtError:
@@ -44,7 +50,7 @@ for seed in range(first, first + count):
         try:
             img = pt.render_epoch(seed, 3, spp)
         except srt_amd.SrtError as e:
-            if "objects" in str(e) or "needs" in str(e):       # kernel does not take this scene (too many objects)
+            if "objects" in str(e) or "needs" in str(e) or "does not take" in str(e) or "not apply" in str(e):   # kernel does not take this scene
                 continue
             raise
         rays[label] = pt.ray_count()[0]
