@@ -308,7 +308,12 @@ __device__ __forceinline__ float4 sample_image(const ImageAux& A, const uint8_t*
 // TSY: tile height in samples (16: 8 KiB of LDS per tile and twice the waves per CU - the kernel is bound by the
 // latency of a wave's own instruction stream, not by throughput - and tighter culling; 32 for sample rates > 16).
 template <bool STATS, int TSY>
-__global__ __launch_bounds__(WAVE) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
+// (five waves per SIMD where the tile's LDS leaves room for them - 96 VGPRs, 7 spilled: 8-sample-high tiles at 20 waves per CU
+//  measure 6 % faster on cfg2 than 16-high ones at 16; six and eight waves per SIMD lose to their spills)
+#ifndef SRT_RASTER_OCC
+#define SRT_RASTER_OCC 5
+#endif
+__global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
                                                      const uint32_t* __restrict__ counts,
@@ -551,9 +556,47 @@ struct srt_raster {
 
 namespace {
 
+// Tile height for this frame.  8-sample-high tiles (4 KiB of LDS, 20 waves per CU) win when the primitives are small (cfg2:
+// 0.189 -> 0.178 ms) or the target has too few 16-high tiles to fill the chip (512^2 x 2: 1.46 -> 0.97 ms on the stress SVG);
+// frames of large primitives on a big target double their (primitive, tile) entries with the smaller tiles and are better
+// off with 16 (1024^2 x 4 stress SVG: 6.9 vs 7.6 ms).  Decided on the host from the target size and the mean bounding-box area
+// of a sample of the stream; the image does not depend on it.
+uint32_t choose_tile_height(const srt_raster* r) {
+  const uint32_t sr = r->P.sr;
+  if (sr > 16) return TS;
+  if (sr > 8) return 16;
+  if (const char* e = getenv("SRT_RASTER_TSY")) { const uint32_t v = (uint32_t)atoi(e); if ((v == 8 || v == 16 || v == 32) && sr <= v) return v; }   // experiments
+  const uint64_t tiles16 = (uint64_t)r->P.tiles_x * ((r->P.h + 16 / sr - 1) / (16 / sr));
+  if (tiles16 < 8192) return 8;
+  const size_t n = r->pending.size();
+  if (n == 0) return 8;
+  const size_t step = n > 2048 ? n / 2048 : 1;
+  double area = 0.0; size_t seen = 0;
+  for (size_t i = 0; i < n; i += step, seen++) {
+    const srt_prim& p = r->pending[i];
+    if (p.kind == SRT_PRIM_POINT) { area += 1.0; continue; }
+    float x0 = p.v.tri[0], x1 = p.v.tri[0], y0 = p.v.tri[1], y1 = p.v.tri[1];
+    const int nv = p.kind == SRT_PRIM_TRIANGLE ? 3 : 2;
+    for (int k = 1; k < nv; k++) { x0 = std::min(x0, p.v.tri[2 * k]); x1 = std::max(x1, p.v.tri[2 * k]); y0 = std::min(y0, p.v.tri[2 * k + 1]); y1 = std::max(y1, p.v.tri[2 * k + 1]); }
+    x0 = std::max(x0, 0.0f); y0 = std::max(y0, 0.0f); x1 = std::min(x1, (float)r->P.w); y1 = std::min(y1, (float)r->P.h);
+    if (x1 > x0 && y1 > y0) area += (double)(x1 - x0) * (double)(y1 - y0);
+  }
+  const double mean_samples = area / (double)seen * (double)sr * (double)sr;
+  return mean_samples > 8192.0 ? 16u : 8u;                 // (sixteen 32 x 16 tiles' worth)
+}
+
 int upload_stream(srt_raster* r) {
   const size_t n = r->pending.size();
   if (n > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32-1 primitives in one frame");
+  {
+    const uint32_t tsy = choose_tile_height(r);
+    if (tsy / r->P.sr * r->P.sr != r->P.tile_sy) {
+      r->P.tile_py = tsy / r->P.sr;
+      r->P.tile_sy = r->P.tile_py * r->P.sr;
+      r->P.tiles_y = (r->P.h + r->P.tile_py - 1) / r->P.tile_py;
+      r->bins_dirty = true;
+    }
+  }
   if (n > r->d_cap) {
     if (r->d_prims) SRT_HIP(hipFree(r->d_prims));
     if (r->d_bbox) SRT_HIP(hipFree(r->d_bbox));
@@ -847,8 +890,7 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   P.ssw = width * sample_rate; P.ssh = height * sample_rate;
   P.tile_px = TS / sample_rate;
   P.tile_s = P.tile_px * sample_rate;
-  uint32_t tsy = sample_rate <= 16 ? 16 : TS;
-  if (getenv("SRT_RASTER_TSY")) { const uint32_t e = (uint32_t)atoi(getenv("SRT_RASTER_TSY")); if ((e == 8 || e == 16 || e == 32) && sample_rate <= e) tsy = e; }   // experiments
+  const uint32_t tsy = sample_rate <= 8 ? 8 : (sample_rate <= 16 ? 16 : TS);   // (re-decided per frame: choose_tile_height)
   P.tile_py = tsy / sample_rate;
   P.tile_sy = P.tile_py * sample_rate;
   P.tiles_x = (width + P.tile_px - 1) / P.tile_px;
