@@ -360,7 +360,11 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
       if (F.mode == FM_UNWIND) {
 #pragma nounroll
         for (uint32_t k = 0; k < P.pops && F.mode == FM_UNWIND; k++) cast_unwind_step<WALK>(F, stack);   // (a second pop costs less than another trip)
-      } else if (at_walk) flat_interior<LdsStack, WALK ? 1 : -1>(F, stack, S);
+      }
+      // (pops first, then the interior step for every lane that stands at an interior node NOW - also the ones a pop has just
+      //  sent into a farther child: they would otherwise idle through this trip's interior code and come back for the next)
+      if (!WALK) cast_enter_leaf_objects(F);
+      if (F.mode == FM_NODE && F.cur >= 0) flat_interior<LdsStack, WALK ? 1 : -1>(F, stack, S);
       if (!WALK) cast_enter_leaf_objects(F);
       CAST_STAT(CS_T_INTERIOR, __builtin_readcyclecounter() - t0);
     } else if (run_obj) {
