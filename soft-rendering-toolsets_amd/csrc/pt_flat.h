@@ -67,6 +67,7 @@ struct FlatState {
   uint32_t obj_i = 0, obj_end = 0;          // objects of the current TLAS leaf still to do
   uint32_t rec_base = 0, tri_base = 0;      // of the mesh being walked
   bool xf = false;                          // ... and whether it has a transform
+  bool inv_ok = false;                      // (walk requests only) cinv is finite in every component: set once per request
   Hit acc, ret;                             // leaf accumulator (TLAS level) / result of the subtree just finished
   Hit res0, res1, res2;
 };
@@ -131,7 +132,7 @@ SRT_DEV void flat_interior(FlatState& F, const StackT& stack, const DScene& S) {
     const bool hb = hl && hr;
     const bool cl = hb ? (t1x < t2x) : hl;     // both hit: smaller entry time first, ties go right
     const int32_t far_ref = cl ? rref : lref;
-    const bool inv_finite = finite_f(F.cinv.x) && finite_f(F.cinv.y) && finite_f(F.cinv.z);
+    const bool inv_finite = LEVEL == 1 ? F.inv_ok : (finite_f(F.cinv.x) && finite_f(F.cinv.y) && finite_f(F.cinv.z));
     if (hb || far_ref < 0 || !inv_finite) {
       FlatFrame f;
       f.second = far_ref;

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
             F.act1 = false; F.act2 = false; F.r = 0u;
             F.co = wo; F.cd = wd; F.b0 = wb0; F.b1 = wb1;
             F.cinv = v3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+            F.inv_ok = finite_f(F.cinv.x) && finite_f(F.cinv.y) && finite_f(F.cinv.z);
             const float dn = norm(wd);
             F.tx = wb0 / dn; F.ty = wb1 / dn;
             F.level = 1; F.rec_base = o.rec_base; F.tri_base = o.tri_base; F.xf = o.has_trans != 0u;
