@@ -10,6 +10,28 @@ import glob
 import json
 import os
 import shutil
+
+
+def keep_counters(src, dst, max_rows=4000):
+    """Copies a rocprofv3 counter_collection.csv into profiles/.  A launch of the streamed forms is ~1000 kernel dispatches
+    and a raw file runs to 10 MB: beyond `max_rows` rows the file is reduced to one row per (kernel, counter) - dispatches,
+    sum, mean, min, max of Counter_Value - which is all make_traffic / bench.py read from it."""
+    import csv
+    rows = list(csv.DictReader(open(src)))
+    if len(rows) <= max_rows:
+        shutil.copy(src, dst)
+        return
+    acc = {}
+    for r in rows:
+        k = (r["Kernel_Name"], r["Counter_Name"])
+        v = float(r["Counter_Value"])
+        a = acc.setdefault(k, [0, 0.0, v, v])
+        a[0] += 1; a[1] += v; a[2] = min(a[2], v); a[3] = max(a[3], v)
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Sum", "Mean", "Min", "Max"])
+        for (kn, cn), (n, sm, mn, mx) in sorted(acc.items()):
+            w.writerow([kn, cn, n, repr(sm), repr(sm / n), repr(mn), repr(mx)])
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,8 +70,8 @@ def main():
     fetch = find(out, "fetch", "counter_collection.csv")
     write = find(out, "write", "counter_collection.csv")
     shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
-    shutil.copy(fetch, f"profiles/{tag}_pmc_fetch_size.csv")
-    shutil.copy(write, f"profiles/{tag}_pmc_write_size_l2.csv")
+    keep_counters(fetch, f"profiles/{tag}_pmc_fetch_size.csv")
+    keep_counters(write, f"profiles/{tag}_pmc_write_size_l2.csv")
     f = per_epoch(fetch, epochs)
     w = per_epoch(write, epochs)
     kernels = {}
@@ -81,7 +103,7 @@ def main():
         sq = {}
         for sub, name in (("a", "pmc_sq_a"), ("b", "pmc_sq_b")):
             path = find(sq_dir, sub, "counter_collection.csv")
-            shutil.copy(path, f"profiles/{tag}_{name}.csv")
+            keep_counters(path, f"profiles/{tag}_{name}.csv")
             sq.update(per_epoch(path, epochs))
         doc["sq_per_launch"] = {k: sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
                                                    "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
