@@ -178,8 +178,8 @@ int srt_pt_accumulate_device(srt_pt* pt, void* stream, float* d_accumulator, con
                              uint32_t accumulator_samples);
 
 /* Kernel selection for render_epoch*: 0 = automatic (default: the persistent wave kernel with wave-uniform
- * sweeps for scenes of <= 16 objects whose meshes are single BVH leaves, else the per-lane kernel with one lane
- * per sample), 1 = per-lane kernel, one lane per pixel (any scene), 2 = persistent wave kernel with wave-uniform
+ * sweeps for scenes of <= 16 objects whose meshes are single BVH leaves - the Cornell boxes -, the streamed forms 7 / 6
+ * for scenes with a real BVH<Triangle> or more objects, the per-lane kernel with one lane per sample for what is left), 1 = per-lane kernel, one lane per pixel (any scene), 2 = persistent wave kernel with wave-uniform
  * sweeps (<= 16 objects; fails otherwise), 3 = the same with in-kernel section stamps (diagnostic build, slower),
  * 4 = per-lane kernel, one lane per sample (any scene), 5 = persistent wave kernel with the flattened per-lane
  * walk of both tree levels (<= 31 objects; fails otherwise; srt_pt_hit then also goes through that walk),
