@@ -645,8 +645,9 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     pt->cast_kern = ckern;
     int cus = 0;
     SRT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pt->device));
-    // 13 frames of 12 bytes x 64 lanes: 16 waves per CU (what the kernel's registers allow) fit into the 160 KB
-    const uint32_t lds_max = getenv("SRT_CAST_LDS_FRAMES") ? (uint32_t)atoi(getenv("SRT_CAST_LDS_FRAMES")) : 13u;
+    // 13 frames of 12 bytes x 64 lanes: 16 waves per CU fit into the 160 KB (what the general build's ~100 VGPRs allow); the
+    // walk-only build needs 85 VGPRs - five waves per SIMD - and takes 10 frames for 20 waves per CU (cast 138 -> 132 ms)
+    const uint32_t lds_max = getenv("SRT_CAST_LDS_FRAMES") ? (uint32_t)atoi(getenv("SRT_CAST_LDS_FRAMES")) : (trav == 4 ? 10u : 13u);
     const uint32_t lds_frames = depth < lds_max ? depth : (lds_max < 1u ? 1u : lds_max);
     const size_t per_wave = (size_t)lds_frames * 3u * 64u * sizeof(uint32_t);
     int best_waves = 0;
@@ -730,7 +731,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       C.depth = depth; C.lds_frames = pt->cast_lds_frames; C.spill = B.d_cast_spill; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
       C.walk_nr = trav == 4 ? burst : 0u;
       for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];
-      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 8u;
+      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : (trav == 4 ? 16u : 8u);   // (walk requests: finished lanes count, see pt_cast_kernel)
       C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
       if (C.fetch_min < 1u) C.fetch_min = 1u;
       C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 12u;

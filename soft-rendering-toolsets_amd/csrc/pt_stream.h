@@ -247,9 +247,12 @@ SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
 #ifndef SRT_CAST_OCC
 #define SRT_CAST_OCC 4
 #endif
+#ifndef SRT_CAST_OCC_WALK
+#define SRT_CAST_OCC_WALK 5
+#endif
 // WALK: the entries are walk requests of the streamed sweeps (P.walk_nr > 0) - no lane ever stands in the top-level tree.
 template <bool STATS, bool WALK>
-__global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, CastParams P) {
+__global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
   const uint32_t nrays = *P.nrays;
   if (nrays == 0u) {
@@ -287,8 +290,32 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
     CAST_STAT(CS_OUTER, 1); CAST_STAT(CS_WALKING_LANES, 64u - nidle);
     unsigned long long t0 = 0;
     if (STATS) t0 = __builtin_readcyclecounter();
-    if (nidle == 64u || (!exhausted && nidle >= P.fetch_min)) {
+    const bool run_leaf = n_leaf >= P.leaf_min || (n_walk == 0u && n_leaf > n_obj);
+    // Walk requests: a lane whose tree is finished (FM_OBJECT) is RETIRED in the fetch phase itself - world distance, result,
+    // and the lane takes the next request in the same trip - instead of waiting for an object phase twice (tree -> mesh,
+    // mesh -> ray) and then for the fetch: lanes in FM_OBJECT count as idle for the fetch threshold.
+    const uint32_t nret = WALK ? nidle + n_obj : nidle;
+    const bool retire = WALK && n_obj > 0u && (n_obj >= P.object_min || (n_walk == 0u && !run_leaf));
+    if (nidle == 64u || (!exhausted && nret >= P.fetch_min) || retire) {
       CAST_STAT(CS_FETCH, 1);
+      if (WALK && at_obj) {
+        // Object::hit's tail for the mesh (flat_exit): the winner's world distance as Trace::transform recomputes it
+        bool hit = F.ret.hit; float dist = F.ret.dist; const uint32_t tri = F.ret.tri;
+        if (hit && F.xf) {
+          const Object& o = S.objects[F.obj_i];
+          Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
+          const TriHit th = tri_hit(S.tris[tri], ray);
+          const V3 pw = mat_point(o.trans, ray_at(ray, th.t));
+          const V3 ow = mat_point(o.trans, ray.o);
+          dist = norm(pw - ow);
+        }
+        Hit acc = flat_no_hit();
+        fold(acc, hit, dist, F.obj_i, tri);
+        F.res0 = acc;
+        F.mode = FM_DONE;
+      }
+      const unsigned long long idle = __ballot(F.mode == FM_DONE);   // (after the retirements)
+      const uint32_t nidle = (uint32_t)__popcll(idle);
       if (have && F.mode == FM_DONE) {                    // results out: every idle lane at once
         const Hit h = F.res0;
         uint2 o;
@@ -354,8 +381,7 @@ __global__ __launch_bounds__(256, SRT_CAST_OCC) void pt_cast_kernel(DScene S, Ca
       if (__ballot(F.mode != FM_DONE) == 0ull && exhausted) break;
       continue;
     }
-    const bool run_leaf = n_leaf >= P.leaf_min || (n_walk == 0u && n_leaf > n_obj);
-    const bool run_obj = !run_leaf && (n_obj >= P.object_min || n_walk == 0u);
+    const bool run_obj = !WALK && !run_leaf && (n_obj >= P.object_min || n_walk == 0u);
     if (!run_leaf && !run_obj) {
       CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_walk);
       if (F.mode == FM_UNWIND) {
