@@ -308,7 +308,7 @@ def pt_roofline(cnt, rays_per_launch, kernel_ms, doc, why_not, kernel, scratch_b
     return out
 
 
-def cfg5_bench(device, args, steps=2):
+def cfg5_bench(device, args, steps=4):
     """BASELINE configs[4]'s workload on one GPU as a second object of the line: the Cornell box with a 131 072-triangle glass
     mesh (80 127-node BVH<Triangle>, depth 18) and the mirror sphere, 1024 x 1024, 64 spp per step.  The streamed sweeps
     (kernel mode 7): wave-uniform sweeps in the logic kernel, the mesh's walks queued to the persistent ray-cast kernel."""
