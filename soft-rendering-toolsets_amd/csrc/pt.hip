@@ -731,11 +731,11 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       C.depth = depth; C.lds_frames = pt->cast_lds_frames; C.spill = B.d_cast_spill; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
       C.walk_nr = trav == 4 ? burst : 0u;
       for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];
-      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : (trav == 4 ? 16u : 8u);   // (walk requests: finished lanes count, see pt_cast_kernel)
+      C.fetch_min = getenv("SRT_CAST_FETCH") ? (uint32_t)atoi(getenv("SRT_CAST_FETCH")) : 16u;
       C.interior_min = getenv("SRT_CAST_INTERIOR") ? (uint32_t)atoi(getenv("SRT_CAST_INTERIOR")) : 16u;
       if (C.fetch_min < 1u) C.fetch_min = 1u;
       C.leaf_min = getenv("SRT_CAST_LEAF") ? (uint32_t)atoi(getenv("SRT_CAST_LEAF")) : 12u;
-      C.object_min = getenv("SRT_CAST_OBJECT") ? (uint32_t)atoi(getenv("SRT_CAST_OBJECT")) : 16u;
+      C.object_min = getenv("SRT_CAST_OBJECT") ? (uint32_t)atoi(getenv("SRT_CAST_OBJECT")) : (trav == 4 ? 16u : 24u);
       C.own_share = getenv("SRT_CAST_OWN") ? (uint32_t)atoi(getenv("SRT_CAST_OWN")) : 128u;
       C.grab = getenv("SRT_CAST_GRAB") ? (uint32_t)atoi(getenv("SRT_CAST_GRAB")) : 32u;
       if (C.grab < 1u) C.grab = 1u;
