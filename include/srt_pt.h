@@ -128,7 +128,8 @@ int srt_pt_add_light(srt_pt* pt, uint32_t type, const float radiance[3], const f
 int srt_pt_set_env_light(srt_pt* pt, uint32_t type, const float radiance[3]);
 /* Env_Map (an HDR_Image as environment): rgb = width * height * 3 floats, pixel (x, y) at index y * width + x as in
  * HDR_Image::at.  As in the reference fork, directions are sampled uniformly (pdf 1 / 4 PI) and Env_Map::evaluate
- * looks the image up bilinearly (student/env_light.cpp:7-93).  Per-lane kernels only. */
+ * looks the image up bilinearly (student/env_light.cpp:7-93).  Every kernel form takes it (the wave kernel's DL build looks the map
+ * up from the regenerated camera direction when a sample that left the scene is resolved). */
 #define SRT_ENV_MAP 3u
 int srt_pt_set_env_map(srt_pt* pt, uint32_t width, uint32_t height, const float* rgb);
 
@@ -141,8 +142,8 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
  * environment forces the host build. */
 int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives);
 /* The streamed forms (kernel modes 6 / 7, what auto takes for scenes with a real BVH<Triangle> or many objects) keep this many
- * paths in flight per launch (rounded up to 256; 0 = the default, 2 Mi; ~1 KB of device memory per slot).  The image does not
- * depend on it. */
+ * paths in flight per launch (rounded up to 256; 0 = the default, 2 Mi; at most 2^26, SRT_ERR_INVALID beyond; ~1 KB of device
+ * memory per slot).  The image does not depend on it. */
 int srt_pt_set_stream_slots(srt_pt* pt, uint32_t slots);
 
 int srt_pt_set_camera(srt_pt* pt, const float iview[16], float vert_fov_deg, float aspect_ratio);
@@ -200,10 +201,11 @@ int srt_pt_section_cycles(srt_pt* pt, uint64_t out[8], int reset);
  * recording on (enable != 0) or off.  Off by default. */
 int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launches);
 
-/* Streamed forms (kernel modes 6, 7) only: device time of the three kernels of a generation - {logic, compaction, ray cast} - summed
- * over every generation launched since the previous call (HIP events around each launch, on the launch stream; waits for them),
- * and the number of generations enqueued; then switches recording on (enable != 0) or off.  Off by default: a diagnostic. */
-int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[3], uint64_t* generations);
+/* Streamed forms (kernel modes 6, 7) only: device time of the kernels of a generation - {logic (the resolve kernel where the
+ * generation is split), compaction, ray cast, probe (0 where logic is one kernel)} - summed over every generation launched since
+ * the previous call (HIP events around each launch, on the launch stream; waits for them), and the number of generations
+ * enqueued; then switches recording on (enable != 0) or off.  Off by default: a diagnostic. */
+int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[4], uint64_t* generations);
 /* Which form render_epoch* takes for the committed scene under the current kernel mode: 0 persistent wave kernel with sweeps,
  * 1 the same with inline BVH<Triangle> walks, 2 persistent waves with the flattened walk, 3 streamed (every ray through the
  * ray-cast kernel), 4 streamed sweeps (BVH<Triangle> walks queued), -1 lane per sample, -2 lane per pixel. */
@@ -279,6 +281,8 @@ int srt_pt_math_pow(srt_pt* pt, const float* x, const float* y, size_t n, float*
  * num2[3i].  Parity tests compare the planes with the host's correctly rounded `/` and sqrtf. */
 int srt_pt_math_div_sqrt(srt_pt* pt, const float* in, size_t lanes, int shared_c2, float* out);
 
+/* Waits for the context's own stream.  Like srt_pt_render_epoch and srt_pt_ray_count it returns SRT_ERR_STATE (once) when a
+ * streamed launch since the last such call ended with unfinished work units - the epoch image of that launch is invalid. */
 int srt_pt_sync(srt_pt* pt);
 
 #ifdef __cplusplus

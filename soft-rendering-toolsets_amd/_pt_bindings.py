@@ -274,11 +274,12 @@ class Pathtracer:
         return ms.value, n.value
 
     def stream_times(self, enable: bool = True):
-        """({"logic_ms", "compact_ms", "cast_ms"}, generations) of the streamed forms since the previous call; then recording on/off."""
-        ms = np.zeros(3, np.float64)
+        """({"logic_ms", "compact_ms", "cast_ms", "probe_ms"}, generations) of the streamed forms since the previous call; then
+        recording on/off.  logic_ms is the resolve kernel where a generation's logic is split in two (probe_ms is 0 otherwise)."""
+        ms = np.zeros(4, np.float64)
         g = c_uint64()
         self._check(self._lib, self._lib.srt_pt_stream_times(self._ctx, int(enable), _p(ms), ctypes.byref(g)))
-        return {"logic_ms": float(ms[0]), "compact_ms": float(ms[1]), "cast_ms": float(ms[2])}, int(g.value)
+        return {"logic_ms": float(ms[0]), "compact_ms": float(ms[1]), "cast_ms": float(ms[2]), "probe_ms": float(ms[3])}, int(g.value)
 
     def kernel_form(self) -> int:
         """Form render_epoch takes for the committed scene: 0 / 1 persistent sweeps (1: inline mesh walks), 2 flattened walk,

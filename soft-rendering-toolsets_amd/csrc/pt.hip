@@ -342,6 +342,8 @@ struct srt_pt {
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
+  uint32_t* h_fault = nullptr;              // pinned, device-visible: bit 0 = a streamed launch ended with unfinished units (sticky until reported)
+  uint32_t* d_fault = nullptr;              // its device address
   int elide = 0;                            // srt_pt_set_elision
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
@@ -351,7 +353,7 @@ struct srt_pt {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> spare;
   // srt_pt_stream_times: per-kernel event pairs of the streamed form {logic, compaction, ray cast}
   bool stream_timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> stream_timed[3];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> stream_timed[4];   // {logic (resolve), compaction, ray cast, probe}
   uint64_t stream_generations = 0;
 };
 
@@ -370,6 +372,15 @@ int need_device(srt_pt* pt, const char* what) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "%s: NULL context", what);
   if (pt->device < 0) return srt::fail(SRT_ERR_NO_DEVICE, "%s needs a HIP device; this context is host-only and there is no CPU fallback", what);
   SRT_HIP(hipSetDevice(pt->device));
+  return SRT_OK;
+}
+
+// After a synchronisation: did a streamed launch end with unfinished units (pt_stream_finish_kernel)?  Reported once.
+int check_stream_fault(srt_pt* pt, const char* what) {
+  if (pt->h_fault && *(volatile uint32_t*)pt->h_fault != 0u) {
+    *(volatile uint32_t*)pt->h_fault = 0u;
+    return srt::fail(SRT_ERR_STATE, "%s: a streamed launch ended before every work unit was finished (generation bound too small); the epoch's image is invalid", what);
+  }
   return SRT_OK;
 }
 
@@ -676,7 +687,11 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   const size_t lds_per_wave = (size_t)(nq > 0 ? nq - 1 : 0) * (2 * burst) * 64 * sizeof(float);
   const uint32_t lthreads = kStreamBlock;
   const size_t logic_lds = (size_t)(lthreads / 64u) * lds_per_wave;
-  const void* lkern = trav == 4 ? (two ? (const void*)pt_wave_kernel<false, 4, false, 2> : dl ? (const void*)pt_wave_kernel<false, 4, true, 3> : (const void*)pt_wave_kernel<false, 4, false, 3>)
+  // the streamed sweeps without delta / environment lights run a generation's two passes as two kernels (pt_wave.h, PHASE):
+  // resolve (sweep slots in LDS) and probe (no LDS); SRT_STREAM_FUSED=1 (diagnostic) keeps them in one kernel
+  const bool split = trav == 4 && !dl && !getenv("SRT_STREAM_FUSED");
+  const void* lkern = trav == 4 ? (two ? (split ? (const void*)pt_wave_kernel<false, 4, false, 2, 1> : (const void*)pt_wave_kernel<false, 4, false, 2>) : dl ? (const void*)pt_wave_kernel<false, 4, true, 3>
+                                           : (split ? (const void*)pt_wave_kernel<false, 4, false, 3, 1> : (const void*)pt_wave_kernel<false, 4, false, 3>))
                                 : (two ? (const void*)pt_wave_kernel<false, 3, false, 2> : dl ? (const void*)pt_wave_kernel<false, 3, true, 3> : (const void*)pt_wave_kernel<false, 3, false, 3>);
   if (logic_lds > 160u * 1024u) return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed sweeps' LDS slots (%zu bytes) do not fit", logic_lds);
   SRT_HIP(hipFuncSetAttribute(lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)logic_lds));
@@ -698,10 +713,16 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     P.units3 = px * P.groups3;
     P.total_units = px * (P.groups3 + P.singles);
     // path slots: every unit its own while they are few, else a fixed population that is refilled from the unit queue
-    uint32_t want_slots = pt->stream_slots ? pt->stream_slots : (getenv("SRT_STREAM_SLOTS") ? (uint32_t)atoi(getenv("SRT_STREAM_SLOTS")) : (1u << 21));
+    uint64_t want_slots = pt->stream_slots ? pt->stream_slots : (1u << 21);
+    if (!pt->stream_slots && getenv("SRT_STREAM_SLOTS")) {    // diagnostic override; anything outside [1, kMaxStreamSlots] is ignored
+      const long long v = atoll(getenv("SRT_STREAM_SLOTS"));
+      if (v >= 1 && v <= (long long)kMaxStreamSlots) want_slots = (uint64_t)v;
+    }
     if (want_slots < lthreads) want_slots = lthreads;
+    if (want_slots > kMaxStreamSlots) want_slots = kMaxStreamSlots;
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(((uint64_t)P.total_units + lthreads - 1) / lthreads * lthreads,
                                                          (want_slots + lthreads - 1) / lthreads * lthreads);
+    if (n && !nlanes) return srt::fail(SRT_ERR_STATE, "streamed launch with %u samples but no path slots (units %u)", n, P.total_units);
     if (n && nlanes) {
       P.nlanes = nlanes;
       const uint32_t nblocks = nlanes / lthreads;
@@ -753,10 +774,21 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   pt_wave_kernel<false, TRAV_, DL_, NR_><<<lgrid, lblock, logic_lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes,         \
                                                                           DS.lights, DS.light_tris, DS.materials, DS.wave_tlas,    \
                                                                           DS.blas_recs, P.records, P.sample_out)
+#define SRT_LAUNCH_PHASE(NR_, PHASE_, LDS_)                                                                                         \
+  pt_wave_kernel<false, 4, false, NR_, PHASE_><<<lgrid, lblock, LDS_, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm, DS.nodes,        \
+                                                                           DS.lights, DS.light_tris, DS.materials, DS.wave_tlas,   \
+                                                                           DS.blas_recs, P.records, P.sample_out)
         if ((st = stream_time_begin(pt, s, 0)) != SRT_OK) return st;
-        if (trav == 4) { if (two) SRT_LAUNCH_LOGIC(4, false, 2); else if (dl) SRT_LAUNCH_LOGIC(4, true, 3); else SRT_LAUNCH_LOGIC(4, false, 3); }
+        if (split) {
+          if (two) SRT_LAUNCH_PHASE(2, 1, logic_lds); else SRT_LAUNCH_PHASE(3, 1, logic_lds);
+          if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 3)) != SRT_OK) return st;
+          if (two) SRT_LAUNCH_PHASE(2, 2, 0); else SRT_LAUNCH_PHASE(3, 2, 0);
+          if ((st = stream_time_end(pt, s, 3)) != SRT_OK || (st = stream_time_begin(pt, s, 0)) != SRT_OK) return st;   // (an empty bracket closes slot 0 below)
+        }
+        else if (trav == 4) { if (two) SRT_LAUNCH_LOGIC(4, false, 2); else if (dl) SRT_LAUNCH_LOGIC(4, true, 3); else SRT_LAUNCH_LOGIC(4, false, 3); }
         else { if (two) SRT_LAUNCH_LOGIC(3, false, 2); else if (dl) SRT_LAUNCH_LOGIC(3, true, 3); else SRT_LAUNCH_LOGIC(3, false, 3); }
 #undef SRT_LAUNCH_LOGIC
+#undef SRT_LAUNCH_PHASE
         if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 1)) != SRT_OK) return st;
         pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id);
         if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
@@ -767,7 +799,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
         if ((st = stream_time_end(pt, s, 2)) != SRT_OK) return st;
       }
       if (pt->stream_timing) pt->stream_generations += gens;
-      pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT);
+      pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT, B.d_sc, pt->d_fault);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
@@ -826,10 +858,13 @@ int srt_pt_create(int device, srt_pt** out) {
     if (device >= count) { delete pt; return srt::fail(SRT_ERR_INVALID, "device %d out of range [0,%d)", device, count); }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pt->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&pt->d_totals, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc((void**)&pt->h_fault, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&pt->d_fault, pt->h_fault, 0) != hipSuccess ||
         hipMemset(pt->d_totals, 0, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess) {
       delete pt;
       return srt::fail(SRT_ERR_HIP, "HIP context setup failed on device %d", device);
     }
+    *pt->h_fault = 0u;
     pt->device = device;
   }
   *out = pt;
@@ -852,6 +887,7 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_wave_lazy); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
+    if (pt->h_fault) (void)hipHostFree(pt->h_fault);
     for (auto& kv : pt->epoch_buffers) {
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
       (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id); (void)hipFree(kv.second.d_cast_spill);
@@ -1005,6 +1041,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
 
 int srt_pt_set_stream_slots(srt_pt* pt, uint32_t slots) {
   if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_stream_slots: NULL context");
+  if (slots > kMaxStreamSlots) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_stream_slots: at most %u path slots (got %u)", kMaxStreamSlots, slots);
   pt->stream_slots = slots;
   return SRT_OK;
 }
@@ -1148,6 +1185,7 @@ int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_
   std::vector<float> host(per_tile * T.local_tiles);
   if (!host.empty()) SRT_HIP(hipMemcpyAsync(host.data(), pt->d_tile_buf, host.size() * sizeof(float), hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
+  if ((st = check_stream_fault(pt, "srt_pt_render_epoch")) != SRT_OK) return st;
   for (uint32_t k = 0; k < T.local_tiles; k++) {
     const uint32_t tile = T.rank + k * T.world;
     const uint32_t x0 = (tile % T.tiles_x) * T.tile_w, y0 = (tile / T.tiles_x) * T.tile_h;
@@ -1197,10 +1235,10 @@ int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launc
   return SRT_OK;
 }
 
-int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[3], uint64_t* generations) {
+int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[4], uint64_t* generations) {
   int st = need_device(pt, "srt_pt_stream_times");
   if (st != SRT_OK) return st;
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 4; k++) {
     double sum = 0.0;
     for (auto& ev : pt->stream_timed[k]) {
       SRT_HIP(hipEventSynchronize(ev.second));
@@ -1230,6 +1268,7 @@ int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int r
   int st = need_device(pt, "srt_pt_ray_count");
   if (st != SRT_OK) return st;
   SRT_HIP(hipDeviceSynchronize());  // epochs may be in flight on any stream
+  if ((st = check_stream_fault(pt, "srt_pt_ray_count")) != SRT_OK) return st;
   unsigned long long r = 0;
   SRT_HIP(hipMemcpy(&r, pt->d_totals + C_COUNT, sizeof r, hipMemcpyDeviceToHost));
   if (rays) *rays = r;
@@ -1515,7 +1554,7 @@ int srt_pt_sync(srt_pt* pt) {
   int st = need_device(pt, "srt_pt_sync");
   if (st != SRT_OK) return st;
   SRT_HIP(hipStreamSynchronize(pt->stream));
-  return SRT_OK;
+  return check_stream_fault(pt, "srt_pt_sync");
 }
 
 }  // extern "C"

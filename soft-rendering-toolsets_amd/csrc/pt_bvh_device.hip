@@ -246,7 +246,7 @@ bool build_bvh_device(const float* boxes6, uint32_t n, uint32_t max_leaf, HostBV
   DBox* d_boxes = nullptr; DNode* d_nodes = nullptr;
   uint32_t *d_prim = nullptr, *d_l = nullptr, *d_r = nullptr, *d_child = nullptr, *d_ns = nullptr;
   size_t total = 1;
-  uint32_t first = 0, count = 1;
+  uint32_t first = 0, count = 1, levels = 0;
   out->nodes.clear(); out->prim.clear();
   BVH_HIP(hipMalloc(&d_boxes, (size_t)n * sizeof(DBox)));
   BVH_HIP(hipMalloc(&d_nodes, node_cap * sizeof(DNode)));
@@ -255,6 +255,10 @@ bool build_bvh_device(const float* boxes6, uint32_t n, uint32_t max_leaf, HostBV
   BVH_HIP(hipMemcpy(d_boxes, boxes6, (size_t)n * sizeof(DBox), hipMemcpyHostToDevice));
   bvh_root<<<dim3(1), dim3(1024)>>>(d_nodes, d_prim, d_boxes, n);
   while (count) {
+    // One launch + one blocking read-back per level.  A usable tree is at most 48 levels deep (kMaxBlasDepth; deeper ones are
+    // refused at commit), while a degenerate input - every centre equal - peels one primitive per level: leave those to the
+    // host builder's verdict instead of ~4n round trips.
+    if (++levels > 512u) { ok = false; goto done; }
     uint32_t nsplit = 0;
     bvh_level_plan<<<dim3(1), dim3(1024)>>>(d_nodes, first, count, max_leaf, (uint32_t)total, d_child, d_ns);
     // block size by the level's width (a proxy for its node sizes): a slice of k primitives is walked k / block steps per pass
@@ -276,7 +280,10 @@ bool build_bvh_device(const float* boxes6, uint32_t n, uint32_t max_leaf, HostBV
   BVH_HIP(hipMemcpy(out->prim.data(), d_prim, (size_t)n * 4, hipMemcpyDeviceToHost));
 done:
   (void)hipFree(d_boxes); (void)hipFree(d_nodes); (void)hipFree(d_prim); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_child); (void)hipFree(d_ns);
-  if (!ok) { out->nodes.clear(); out->prim.clear(); }
+  if (!ok) {
+    out->nodes.clear(); out->prim.clear();
+    (void)hipGetLastError();   // the caller falls back to the host build: a failed hipMalloc here must not surface as the error of a later, unrelated launch
+  }
   return ok;
 }
 

@@ -191,12 +191,15 @@ int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sa
   }
   const float* gathered = g->d_tiles[0];
   if (g->use_rccl) {                     // ONE collective per epoch: tile radiance -> rank 0
+    // (no early return between GroupStart and GroupEnd: a failing rank ends the loop, the group is always closed)
     ncclResult_t rc = g->rccl.GroupStart();
-    for (size_t r = 0; r < n && rc == 0; r++) {
-      SRT_HIP(hipSetDevice(g->devices[r]));
-      rc = g->rccl.Gather(g->d_tiles[r], r == 0 ? g->d_gather : nullptr, g->tile_floats, kNcclFloat, 0, g->comms[r], g->streams[r]);
+    hipError_t he = hipSuccess;
+    for (size_t r = 0; r < n && rc == 0 && he == hipSuccess; r++) {
+      he = hipSetDevice(g->devices[r]);
+      if (he == hipSuccess) rc = g->rccl.Gather(g->d_tiles[r], r == 0 ? g->d_gather : nullptr, g->tile_floats, kNcclFloat, 0, g->comms[r], g->streams[r]);
     }
     const ncclResult_t rc2 = g->rccl.GroupEnd();
+    if (he != hipSuccess) return srt::fail(SRT_ERR_HIP, "hipSetDevice inside the gather group failed: %s", hipGetErrorString(he));
     if (rc != 0 || rc2 != 0) return srt::fail(SRT_ERR_HIP, "ncclGather failed: %s", g->rccl.GetErrorString(rc != 0 ? rc : rc2));
     gathered = g->d_gather;
   } else if (n > 1) {                    // ranks that share a device (or no RCCL): device-to-device copies behind events

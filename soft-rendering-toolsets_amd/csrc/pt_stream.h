@@ -179,8 +179,13 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __rest
   (void)nslots;
 }
 
-// After the last generation: the logic blocks' ray counts into the context's totals {rays, rays elided}.
-__global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_counters, uint32_t nblocks, unsigned long long* __restrict__ totals) {
+// After the last generation: the logic blocks' ray counts into the context's totals {rays, rays elided}.  The number of
+// generations the host enqueued is an upper bound derived from the longest chain of batches a unit can need; should it ever be
+// too small (a batch type the bound does not know), units are unfinished and their samples stale: `fault` (host-visible, sticky)
+// is raised and the next synchronising call of the C ABI fails instead of handing out a wrong image.
+__global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_counters, uint32_t nblocks, unsigned long long* __restrict__ totals,
+                                        const StreamCounters* __restrict__ sc, uint32_t* __restrict__ fault) {
+  if (threadIdx.x == 0 && sc->done == 0u) atomicOr(fault, 1u);
   unsigned long long a = 0, b = 0;
   for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x) {
     a += block_counters[2 * (size_t)i]; b += block_counters[2 * (size_t)i + 1];

@@ -85,6 +85,7 @@ struct WaveParams {
 
 constexpr uint32_t kStreamBlock = 256;    // threads per block of the streamed logic kernels (one queue atomic per block; four waves, so
                                           // that a CU takes the next block as soon as four waves are done)
+constexpr uint32_t kMaxStreamSlots = 1u << 26;   // srt_pt_set_stream_slots: upper bound of the path-slot population (state planes: ~13 GB there)
 constexpr uint32_t kMaxLazy = 4;          // TRAV 4: meshes with a real BVH<Triangle> whose walks are queued
 
 // Wave-uniform launch constants passed through an empty asm: the value stays in SGPRs, but arithmetic on it
@@ -449,7 +450,15 @@ template <> struct ColdU32<true> {
 constexpr int kColdWords = 4;
 __host__ __device__ constexpr bool cold_in_lds(int trav) { return trav == 0; }
 
-template <bool STAMP, int TRAV, bool DL, int NR>
+// PHASE (streamed sweeps, TRAV 4, without delta / environment lights): the two passes of a generation as TWO kernels.
+//   1 "resolve": load the slot, complete sweep with the walks' results, finish the bounce, terminate or shade, save.
+//   2 "probe":   load what the next batch's rays need (origin, directions, bounds, flags), refill idle slots from the unit queue,
+//                box-test the nodes above the queued meshes, emit the walk requests, save the emit mask (and a new unit's words).
+//   0: both passes in one kernel (TRAV 3, and the DL build of TRAV 4).
+// One kernel carrying a slot's whole state through both sweeps wanted ~245 VGPRs at four waves per SIMD (121 spilled, ~150 GB of
+// scratch traffic per 64-spp epoch of BASELINE configs[4]); the resolve kernel alone is the Cornell kernel's loop body, and the
+// probe kernel needs neither the sweep slots in LDS nor most of the state.
+template <bool STAMP, int TRAV, bool DL, int NR, int PHASE = 0>
 #ifndef SRT_WAVE_OCC
 #define SRT_WAVE_OCC 4
 #endif
@@ -465,7 +474,10 @@ template <bool STAMP, int TRAV, bool DL, int NR>
 #ifndef SRT_STREAM_OCC
 #define SRT_STREAM_OCC 4
 #endif
-__global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC))) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
+#ifndef SRT_PROBE_OCC
+#define SRT_PROBE_OCC 8
+#endif
+__global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV == 1 ? SRT_WAVE_OCC2T : (TRAV >= 3 ? 4 : SRT_WAVE_OCC2)) : (TRAV == 1 ? SRT_WAVE_OCC3T : SRT_WAVE_OCC))) void pt_wave_kernel(DScene S_in, WaveParams P_in, const Object* __restrict__ a_objects,
                                                       const Tri* __restrict__ a_tris, const TriNrm* __restrict__ a_nrm,
                                                       const Node* __restrict__ a_nodes, const Light* __restrict__ a_lights,
                                                       const LightTri* __restrict__ a_ltris, const Material* __restrict__ a_mats,
@@ -473,6 +485,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
                                                       float* __restrict__ a_records, float* __restrict__ a_samples) {
   static_assert(NR == 3 || (NR == 2 && TRAV != 2 && !DL), "two-ray batches: sweep builds without delta / environment lights only");
   static_assert(!(STAMP && TRAV >= 3), "the streamed builds have no section stamps");
+  static_assert(PHASE == 0 || (TRAV == 4 && !DL), "split generations: the streamed sweeps without delta / environment lights");
   constexpr int C = NR - 1;                              // slot of the indirect ray
   constexpr bool STREAM = TRAV >= 3;                     // pt_stream.h: 3 = every ray through the ray-cast kernel, 4 = sweeps here, BVH<Triangle> walks queued
   constexpr bool LAZY = TRAV == 1 || TRAV == 4;          // meshes with a real BVH<Triangle> are evaluated lazily inside the sweeps
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
   // The root (q = 0) has no slot: it receives no `times` and nobody reads its result; its cur_far_t.x stays in registers.
   constexpr bool COLD = cold_in_lds(TRAV);
   uint32_t* const cold = reinterpret_cast<uint32_t*>(lds_f) + threadIdx.x;           // [variable][thread of the block]
-  float* wl = lds_f + (COLD ? kColdWords * 256 : 0) + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;
+  float* wl = lds_f + (COLD ? kColdWords * 256 : 0) + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;   // (PHASE 2: no dynamic LDS, never touched)
 #define SLOT(q, r, f) wl[((((q) - 1) * NR + (r)) * 2 + (f)) * 64]
 
   const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,7 +590,19 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
 #define REC_STORE(lev, half, x, y, z, w) __builtin_nontemporal_store(f32x4{x, y, z, w}, REC_AT(lev, half))
 #define REC_LOAD(lev, half) (*REC_AT(lev, half))
   uint32_t emit_mask = 0;                                // queue slots of this lane that carry a ray / walk request for the next cast
-  if constexpr (STREAM) {
+  if constexpr (STREAM && PHASE == 2) {
+    // the probe kernel: what the batch's rays need, nothing else
+    const uint32_t fw = ST(SW_FLAGS);
+    alive = (fw & 1u) != 0;
+    if (alive) {
+      burst = (fw & 2u) != 0; actA = (fw & 4u) != 0; actB = (fw & 8u) != 0;
+      org = v3(__uint_as_float(ST(SW_ORG)), __uint_as_float(ST(SW_ORG + 1)), __uint_as_float(ST(SW_ORG + 2)));
+      d[C] = v3(__uint_as_float(ST(SW_DC)), __uint_as_float(ST(SW_DC + 1)), __uint_as_float(ST(SW_DC + 2)));
+      cb0 = __uint_as_float(ST(SW_CB0)); cb1 = __uint_as_float(ST(SW_CB1));
+      d[0] = v3(__uint_as_float(ST(SW_D0)), __uint_as_float(ST(SW_D0 + 1)), __uint_as_float(ST(SW_D0 + 2)));
+      if (NR > 2) d[1] = v3(__uint_as_float(ST(SW_D1)), __uint_as_float(ST(SW_D1 + 1)), __uint_as_float(ST(SW_D1 + 2)));
+    }
+  } else if constexpr (STREAM) {
     if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
     const uint32_t fw = ST(SW_FLAGS);
     alive = (fw & 1u) != 0;
@@ -611,10 +636,27 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
     }
   }
 
+  bool refilled = false;                                 // PHASE 2: the slot took a new unit in this generation
   auto save_state = [&]() {
+    if constexpr (PHASE == 2) {
+      // the probe kernel changes a slot's state only by giving it a new unit: the words the refill sets (the parked hits, the RNG
+      // state and the shading terms are written by the resolve kernel before anything reads them)
+      ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));
+      if (refilled) {
+        ST_SET(SW_FLAGS, 1u | 2u | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (level << 8) | (depth << 16));
+        ST_SET(SW_PX, PX_); ST_SET(SW_PY, PY_); ST_SET(SW_PIXEL_SLOT, pixel_slot);
+        ST_SET(SW_SAMPLES, samp);
+        ST_SET(SW_ORG, __float_as_uint(org.x)); ST_SET(SW_ORG + 1, __float_as_uint(org.y)); ST_SET(SW_ORG + 2, __float_as_uint(org.z));
+        ST_SET(SW_DC, __float_as_uint(d[C].x)); ST_SET(SW_DC + 1, __float_as_uint(d[C].y)); ST_SET(SW_DC + 2, __float_as_uint(d[C].z));
+        ST_SET(SW_CB0, __float_as_uint(cb0)); ST_SET(SW_CB1, __float_as_uint(cb1));
+        ST_SET(SW_D0, __float_as_uint(d[0].x)); ST_SET(SW_D0 + 1, __float_as_uint(d[0].y)); ST_SET(SW_D0 + 2, __float_as_uint(d[0].z));
+        if (NR > 2) { ST_SET(SW_D1, __float_as_uint(d[1].x)); ST_SET(SW_D1 + 1, __float_as_uint(d[1].y)); ST_SET(SW_D1 + 2, __float_as_uint(d[1].z)); }
+      }
+      return;
+    }
     ST_SET(SW_FLAGS, (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
                    (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16));
-    ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));   // (bit 31: the slot is alive - a generation without requests need not be the last)
+    if constexpr (PHASE == 0) ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));   // (bit 31: the slot is alive - a generation without requests need not be the last; PHASE 1: the probe kernel writes it)
     if (alive) {
       ST_SET(SW_PX, PX_); ST_SET(SW_PY, PY_); ST_SET(SW_PIXEL_SLOT, pixel_slot);
       ST_SET(SW_SAMPLES, samp);
@@ -641,11 +683,11 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
     }
   };
 
-  for (int pass = 0;; pass++) {
+  for (int pass = (PHASE == 2 ? 1 : 0);; pass++) {
     // ---------------- 1. refill idle lanes ----------------
-    const unsigned long long need = (!STREAM || pass == 1) ? __ballot(!alive) : 0ull;
+    const unsigned long long need = (!STREAM || (PHASE != 1 && pass == 1)) ? __ballot(!alive) : 0ull;
     uint32_t stream_unit = kMissTri;
-    if constexpr (STREAM) {
+    if constexpr (STREAM && PHASE != 1) {
       if (pass == 1) {
         // one queue atomic per BLOCK: the waves' wants meet in LDS (a single word saturates at ~90 atomics / us, and a
         // generation of a million slots would bring sixteen thousand of them)
@@ -664,7 +706,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
         __syncthreads();                                  // (s_blk is reused below)
       }
     }
-    if ((!STREAM && need != 0ull && !(queue_empty && chunk_next == chunk_end)) || (STREAM && pass == 1)) {
+    if ((!STREAM && need != 0ull && !(queue_empty && chunk_next == chunk_end)) || (STREAM && PHASE != 1 && pass == 1)) {
       const uint32_t want = (uint32_t)__popcll(need);
       const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
       uint32_t given = 0, my_unit = stream_unit;
@@ -719,6 +761,7 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
           actA = u_count > 1;                           // slot usage of a burst: ray j exists iff j < count
           actB = u_count > 2;
           need_begin = true;
+          refilled = true;
         } else {
           units_finished++;                             // a padding pixel of an edge tile: nothing to render
         }
@@ -759,6 +802,47 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
     }
     SECTION_END(ST_REFILL)
 
+    if constexpr (TRAV == 4 && PHASE == 2) {
+      // ---- the probe kernel's whole trace step: which rays of the batch can reach a queued mesh?  A ray needs the walk of mesh m
+      // iff it hits either child box of the node above m's leaf (the fused kernel's probe pass computes exactly this from the
+      // top-down sweep's flags: BBox::hit's verdict does not depend on the `times` handed down, only their narrowing does).
+      bool pact[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) pact[r] = alive;
+      if (burst) { if (NR > 1) pact[1] = alive && actA; if (NR > 2) pact[NR - 1] = alive && actB; }
+      else if (NR == 3) { pact[0] = alive && actA; pact[1] = alive && actB; }
+      float pb0[NR], pb1[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) { pb0[r] = cb0; pb1[r] = cb1; }
+      auto is_lazy = [&](uint32_t k) { const Object& ob = S.objects[k]; return ob.kind == OBJ_MESH && ob.use_bvh != 0u && ob.nrec > 0u; };
+      bool h_[NR]; float dd_[NR]; uint32_t tt_[NR];
+      if (Q == 0) {
+        for (uint32_t k = 0; k < nobj; k++)
+          if (is_lazy(k)) object_queueN<NR>(S, k, org, d, pb0, pb1, h_, dd_, tt_, pact, P, lane_global, true, emit_mask);
+      } else {
+        V3 pinv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) pinv[r] = v3(1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z);
+        for (uint32_t q = 0; q < Q; q++) {
+          const WaveInterior& W = S.wave_tlas[q];
+          const bool lazy_l = W.l_ref < 0 && W.l_cnt == 1u && is_lazy((uint32_t)~W.l_ref);
+          const bool lazy_r = W.r_ref < 0 && W.r_cnt == 1u && is_lazy((uint32_t)~W.r_ref);
+          if (!lazy_l && !lazy_r) continue;
+          bool pneed[NR];
+#pragma unroll
+          for (int r = 0; r < NR; r++) {
+            float ta = 0.0f, tb = 0.0f, tc = 0.0f, td = 0.0f;
+            const bool hl = box_hit_inv(W.boxl, org, pinv[r], ta, tb);
+            const bool hr = box_hit_inv(W.boxr, org, pinv[r], tc, td);
+            pneed[r] = pact[r] && (hl || hr);
+          }
+          if (lazy_l) object_queueN<NR>(S, (uint32_t)~W.l_ref, org, d, pb0, pb1, h_, dd_, tt_, pneed, P, lane_global, true, emit_mask);
+          if (lazy_r) object_queueN<NR>(S, (uint32_t)~W.r_ref, org, d, pb0, pb1, h_, dd_, tt_, pneed, P, lane_global, true, emit_mask);
+        }
+      }
+      save_state();
+      break;
+    }
     // ---------------- 2. trace the batch: scene.hit for slots A, B, C ----------------
     if (TRAV != 2 && !(TRAV == 4 && pass == 1)) {
       if (DL && sh_phase) cnt.v[C_RAYS] += alive ? (1u + (sa1 ? 1u : 0u) + (sa2 ? 1u : 0u)) : 0u;
@@ -1207,6 +1291,10 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
       }
     }
     SECTION_END(ST_SHADE)
+    if constexpr (PHASE == 1) {                          // the resolve kernel: one pass; the probe kernel refills and emits
+      save_state();
+      break;
+    }
   }
   if (STAMP && lane == 0)
     for (int i = 0; i < ST_COUNT_; i++) atomicAdd(&P.stamps[i], stamp_acc[i]);
@@ -1225,7 +1313,9 @@ __global__ __launch_bounds__(256, TRAV == 4 ? SRT_STREAM_OCC : (NR == 2 ? (TRAV 
 #undef S_COUNT_
   unsigned long long r = cnt.v[C_RAYS], rt = (NR == 3) ? cnt.v[C_RAYS] : traced;
   for (int off = 32; off > 0; off >>= 1) { r += __shfl_down(r, off); rt += __shfl_down(rt, off); }
-  if constexpr (STREAM) {
+  if constexpr (STREAM && PHASE == 2) {
+    (void)units_finished;                                // (the probe kernel traces nothing: no rays to count)
+  } else if constexpr (STREAM) {
     // per-block sums into the block's own words (no atomics; pt_stream_finish_kernel adds them up after the last generation)
     (void)units_finished;
     if (lane == 0) { s_blk[wave] = r; s_blk[16 + wave] = r - rt; }

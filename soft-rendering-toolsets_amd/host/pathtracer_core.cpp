@@ -16,12 +16,16 @@ void RenderCore::check(int status, const char* what) const {
 RenderCore::RenderCore(const int* devices, int n, void (*fatal_)(const char*, int, const char*)) : fatal(fatal_) {
     std::vector<int> all;
     if(!devices) {
+        // Default: ONE device (device 0).  More devices are opt-in - the constructor's list or SRT_PT_DEVICES=<count> - because that
+        // routes every epoch through srt_pt_group's distinct-device gather (ncclCommInitAll + grouped ncclGather), which no
+        // hardware run has shown bit-equal to the single context yet (Multi-GPU).
         int count = 0;
         if(hipGetDeviceCount(&count) != hipSuccess || count <= 0) fatal("hipGetDeviceCount", SRT_ERR_NO_DEVICE, "no HIP device: this path has no CPU fallback");
-        if(const char* lim = getenv("SRT_PT_DEVICES")) count = std::max(1, std::min(count, atoi(lim)));
-        for(int d = 0; d < count; d++) all.push_back(d);
+        int use = 1;
+        if(const char* lim = getenv("SRT_PT_DEVICES")) use = std::max(1, std::min(count, atoi(lim)));
+        for(int d = 0; d < use; d++) all.push_back(d);
         devices = all.data();
-        n = count;
+        n = use;
     }
     check(srt_pt_create_multi(devices, n, &group), "srt_pt_create_multi");
     for(int r = 0; r < srt_pt_group_size(group); r++) {

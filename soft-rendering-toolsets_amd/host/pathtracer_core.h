@@ -29,7 +29,7 @@ namespace srt_host {
 
 class RenderCore {
 public:
-    // devices == nullptr: every visible HIP device (SRT_PT_DEVICES=n limits the count).  Aborts through `fatal` when there is
+    // devices == nullptr: device 0 only; SRT_PT_DEVICES=n opts in to the first n visible HIP devices (the distinct-device gather).  Aborts through `fatal` when there is
     // no device: the path has no CPU fallback.
     RenderCore(const int* devices, int n, void (*fatal)(const char* what, int status, const char* message));
     ~RenderCore();

@@ -67,7 +67,7 @@ private:
     void feed_scene(srt_pt* ctx, Scene& scene);  // the object / light / particle walk for one context
 
     Gui::Widget_Render& gui;
-    // Everything that does not need Scene: contexts of every visible GPU (image tiles + one RCCL gather per epoch), the
+    // Everything that does not need Scene: a context group - device 0 by default, more GPUs through SRT_PT_DEVICES=<count> (image tiles + one RCCL gather per epoch), the
     // epoch scheme, the worker, the running mean, cancel / progress, the display epilogue (pathtracer_core.h).
     srt_host::RenderCore core;
 

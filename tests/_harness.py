@@ -204,6 +204,13 @@ def check_blas_against_golden(g, k, dump):
     return False
 
 
+def load_fullsize():
+    """tests/golden/pt_fullsize.json: SHA-256 (+ a crop) of full-size epoch images from the reference build."""
+    import json
+    with open(os.path.join(GOLDEN, "pt_fullsize.json")) as f:
+        return json.load(f)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

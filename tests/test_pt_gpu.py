@@ -477,6 +477,45 @@ def test_full_size_properties(srt):
     pt.close()
 
 
+FULLSIZE = H.load_fullsize()
+
+
+@pytest.mark.parametrize("case", sorted(FULLSIZE), ids=sorted(FULLSIZE))
+def test_full_size_epoch_equals_reference_hash(srt, case):
+    """BASELINE configs[2..4] at their image sizes through the PRODUCTION kernels: `auto` mode with the default population
+    (the persistent wave kernel for the Cornell boxes, the streamed sweeps with 2 Mi path slots for the box + large mesh),
+    with and without dead-ray elision (what the drop-in class runs), and - for the streamed forms - once more with 4096
+    path slots so that every slot is recycled hundreds of times.  Expected: the SHA-256 of the epoch image the REFERENCE's own
+    code (oracle/_ref/libref_pt.so) produced in the authoring container, tests/golden/pt_fullsize.json
+    (make_pt_fullsize_golden.py); nothing of the reference is needed on the GPU box."""
+    g = FULLSIZE[case]
+    scene = pt_scene(g["scene"])
+    assert scene_digest(scene) == g["scene_sha256"]
+    pt = make_pt(srt, scene, g["w"], g["h"], g["max_depth"], True)
+    pt.set_kernel(0)
+
+    def check(what):
+        img = pt.render_epoch(g["seed"], g["sample_base"], g["spp"])
+        fin = np.isfinite(img).all(axis=2)
+        x0, y0 = g["crop_origin"]
+        crop = np.frombuffer(bytes.fromhex(g["crop_hex"]), np.float32).reshape(16, 16, 3)
+        assert int((~fin).sum()) == g["nonfinite_pixels"], what
+        assert bits_equal(img[y0:y0 + 16, x0:x0 + 16], crop), f"{what}: centre crop differs from the reference"
+        assert H.sha(img) == g["sha256"], f"{what}: epoch image differs from the reference (mean {img[fin].mean(dtype=np.float64):.6f} vs {g['mean_finite']:.6f})"
+
+    form = pt.kernel_form()
+    assert form in (0, 4), f"auto mode took kernel form {form} for {case}"
+    check(f"auto (form {form})")
+    pt.set_elision(True)
+    check(f"auto (form {form}) with dead-ray elision")
+    pt.set_elision(False)
+    if form >= 3:
+        pt.set_stream_slots(4096)
+        check("streamed, 4096 path slots")
+        pt.set_stream_slots(0)
+    pt.close()
+
+
 @pytest.mark.parametrize("name,use_bvh,wh,spp,depth", [
     ("cbox", True, (72, 40), 6, 8),               # edge tiles with padding pixels
     ("cbox_lambertian", True, (64, 64), 70, 3),   # > 64 spp: two launches, running (sum, count)

@@ -230,3 +230,22 @@ def test_oracle_matches_reference_build(name, use_bvh):
         rgb, draws, _ = o.trace_samples(123456789, xs, ys, ss)
         assert bits_equal(rgb, r_rgb) and np.array_equal(draws, r_draws)
     assert H.ref_pt_lib().ref_pt_unqualified_sqrt_is_double() == 1  # shapes.cpp's sqrt(delta) is fp64
+
+
+def test_fullsize_fixture_matches_scenes_and_oracle_crop():
+    """tests/golden/pt_fullsize.json (full-size epoch hashes from the reference build): every case refers to the scene
+    description as it is now, and the oracle reproduces the committed centre crop of the two cheapest cases bit for bit
+    (the whole images are compared on the GPU, tests/test_pt_gpu.py::test_full_size_epoch_equals_reference_hash)."""
+    cases = H.load_fullsize()
+    assert {"cfg3_cbox_lambertian_512_64spp", "cfg4_cbox_1024_4spp", "cfg5_blob131072_1024_2spp", "cfg5_beast_1024_2spp"} <= set(cases)
+    for name, g in cases.items():
+        assert scene_digest(pt_scene(g["scene"])) == g["scene_sha256"], name
+        assert len(g["sha256"]) == 64 and len(g["crop_hex"]) == 16 * 16 * 3 * 4 * 2
+    for name in ("cfg4_cbox_1024_4spp", "cfg4_cbox_1024_3spp_base61"):
+        g = cases[name]
+        x0, y0 = g["crop_origin"]
+        o = H.OraclePT(pt_scene(g["scene"]), g["w"], g["h"], g["max_depth"], True)
+        img = np.zeros((g["h"], g["w"], 3), np.float32)
+        o.epoch(g["seed"], g["sample_base"], g["spp"], y0, y0 + 16, img)
+        crop = np.frombuffer(bytes.fromhex(g["crop_hex"]), np.float32).reshape(16, 16, 3)
+        assert bits_equal(img[y0:y0 + 16, x0:x0 + 16], crop), name
