@@ -10,15 +10,17 @@
  *   srt_raster_submit       <- the ordered calls draw_svg/draw_element make into
  *                              rasterize_triangle  src/software_renderer.cpp:456-516 (+ inside_triangle :519-538,
  *                                                   fill_sample :634-658)
+ *                              rasterize_line      src/software_renderer.cpp:303-318 -> rasterize_line_xiaolinwu :365-454
+ *                                                   (expanded into its rasterize_point calls ON THE DEVICE)
  *                              rasterize_point     src/software_renderer.cpp:272-301
  *                              rasterize_image     src/software_renderer.cpp:540-570 (+ Sampler2DImp, src/texture.cpp:145-193)
  *   srt_raster_add_texture  <- the CMU462::Texture of an <image> element after Sampler2D::generate_mips
  *                              (DrawSVG::regenerate_mipmap, src/drawsvg.cpp:462-474)
  *   srt_raster_resolve      <- SoftwareRendererImp::resolve            src/software_renderer.cpp:573-622
  *
- * The host element walk (draw_svg / draw_element / transform stack / Xiaolin-Wu line
- * decomposition, src/software_renderer.cpp:17-52,94-265,303-454) stays on the host: it
- * produces the ORDERED primitive stream that is handed to srt_raster_submit. Painter's
+ * The host element walk (draw_svg / draw_element / transform stack, src/software_renderer.cpp:17-52,94-265)
+ * stays on the host: it produces the ORDERED primitive stream that is handed to srt_raster_submit - one
+ * record per rasterize_triangle / rasterize_line / rasterize_point / rasterize_image call. Painter's
  * order is part of the contract: primitives are blended in stream order.
  *
  * Conventions: every entry point returns 0 on success and a negative srt_status on
@@ -49,8 +51,14 @@ typedef enum srt_status {
 enum {
     SRT_PRIM_TRIANGLE = 1, /* rasterize_triangle(x0,y0,x1,y1,x2,y2,color) — args already narrowed to float */
     SRT_PRIM_POINT = 2,    /* rasterize_point(x,y,color) — args are double, sr*sr block fill */
-    SRT_PRIM_IMAGE = 3     /* rasterize_image(x0,y0,x1,y1,tex) — tri[0..3] = the four float parameters, `reserved` =
+    SRT_PRIM_IMAGE = 3,    /* rasterize_image(x0,y0,x1,y1,tex) — tri[0..3] = the four float parameters, `reserved` =
                               texture id from srt_raster_add_texture; sampled with Sampler2DImp::sample_trilinear */
+    SRT_PRIM_LINE = 4      /* rasterize_line(x0,y0,x1,y1,color) = rasterize_line_xiaolinwu — tri[0..3] = the four float
+                              parameters; rgba[3] is ignored (the reference REPLACES the stroke alpha by the Wu coverage).
+                              The device performs the reference's rasterize_point calls in their order: first end point
+                              (2), second end point (2), then the main loop, whose upper bound subtracts the sample rate
+                              (:434,445).  Lines whose main loop the reference could not walk (|x| >= 2^24, where its
+                              `++x` on a float stops advancing) are refused with SRT_ERR_UNSUPPORTED at resolve. */
 };
 
 #define SRT_MAX_MIP_LEVELS 14 /* kMaxMipLevels, D/src/texture.h:9 */
@@ -60,7 +68,7 @@ typedef struct srt_prim {
     uint32_t kind;
     uint32_t reserved; /* 0; for SRT_PRIM_IMAGE the texture id */
     union {
-        float tri[6];     /* x0 y0 x1 y1 x2 y2 — the six float parameters of rasterize_triangle */
+        float tri[6];     /* x0 y0 x1 y1 x2 y2 — the six float parameters of rasterize_triangle (images, lines: the first four) */
         double point[2];  /* x y — the two double parameters of rasterize_point */
     } v;
     float rgba[4]; /* CMU462::Color r g b a, NOT premultiplied (fill_sample semantics) */
@@ -73,7 +81,7 @@ typedef struct srt_raster_stats_t {
     uint64_t sample_tests;           /* inside_triangle evaluations the reference performs (bbox area, unclipped) */
     uint64_t sample_tests_in_target; /* the subset that lies inside the sample grid (what the kernel evaluates) */
     uint64_t fragments;      /* covered, in-bounds fill_sample calls reached from rasterize_triangle */
-    uint64_t point_samples;  /* in-bounds fill_sample calls reached from rasterize_point */
+    uint64_t point_samples;  /* in-bounds fill_sample calls reached from rasterize_point (directly or through a line) */
     uint64_t bin_entries;    /* (primitive, tile) pairs processed */
     uint64_t list_bytes;     /* device memory held by the two levels of ordered bin lists for this stream / target */
 } srt_raster_stats_t;
@@ -108,6 +116,13 @@ int srt_raster_clear_textures(srt_raster* r);
  * (row 0 = top, row-major) into host memory `rgba8_out`. Synchronous: the buffer is complete on return. */
 int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out);
 
+/* Optional: tell the library that `host_rgba8` (bytes >= width*height*4) is the buffer srt_raster_resolve will be
+ * handed from now on - DrawSVG lends one framebuffer per window size (set_render_target, drawsvg.cpp:107-114).  The
+ * pages are pinned (hipHostRegister), so the read-back of a frame is one DMA transfer instead of a staged pageable
+ * copy.  srt_raster_resolve works with any pointer; a bound one is only faster.  Unbind (or bind another buffer, or
+ * destroy the context) BEFORE the memory is freed.  Binding NULL unbinds. */
+int srt_raster_bind_output(srt_raster* r, uint8_t* host_rgba8, size_t bytes);
+
 /* Same as srt_raster_resolve but leaves the RGBA8 image in device memory (pointer valid until the next
  * set_target/destroy) and does not synchronize the stream; used by the resident-input benchmark.
  * `stream` is the hipStream_t to enqueue on (NULL = the HIP default stream, which is also PyTorch's default). */
@@ -119,6 +134,12 @@ int srt_raster_read_samples(srt_raster* r, float* samples_out);
 
 /* Optional: counters of the last resolve (costs an extra device pass). */
 int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out);
+
+/* The library keeps what it derived from the current stream on the device - bounding boxes, line tables, the ordered bin
+ * lists - and a frame of an unchanged stream on an unchanged target runs the tile kernel alone (DrawSVG redraws on every
+ * event).  srt_raster_invalidate makes the next frame derive them again: benchmarks use it to time a FULL frame
+ * (setup + binning + tiles) of a resident stream. */
+int srt_raster_invalidate(srt_raster* r);
 
 /* Block until all work of the context has finished. */
 int srt_raster_sync(srt_raster* r);

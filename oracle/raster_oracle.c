@@ -114,6 +114,54 @@ static void rasterize_point(oracle_raster* o, double x, double y, const float co
     }
 }
 
+/* ipart / fpart / rfpart, software_renderer.cpp:355-363 (float in, float out) */
+static float wu_ipart(float x) { return floorf(x); }
+static float wu_fpart(float x) { return x - floorf(x); }
+static float wu_rfpart(float x) { return 1 - wu_fpart(x); }
+
+/* rasterize_line (software_renderer.cpp:303-318) = rasterize_line_xiaolinwu, :365-454: the stroke alpha is REPLACED by the
+ * Wu coverage; end points first, then the main loop, whose bound subtracts sample_rate.  Returns -1 where the reference's
+ * `for (float x = ...; x <= last; ++x)` would never end (|x| >= 2^24: ++x no longer advances) - the product refuses those. */
+static int rasterize_line(oracle_raster* o, float x0, float y0, float x1, float y1, const float color_in[4]) {
+    float color[4] = {color_in[0], color_in[1], color_in[2], color_in[3]};
+    const int steep = fabsf(x1 - x0) < fabsf(y1 - y0);
+    float t;
+    if (steep) { t = x0; x0 = y0; y0 = t; t = x1; x1 = y1; y1 = t; }
+    if (x0 > x1) { t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+    const float dx = x1 - x0, dy = y1 - y0;
+    const float gradient = (dx == 0.0f) ? 1.0f : dy / dx;
+    /* first end point */
+    float xend = roundf(x0);
+    float yend = y0 + gradient * (xend - x0);
+    float xgap = wu_rfpart(x0 + 0.5f);
+    const float xpxl1 = xend, ypxl1 = wu_ipart(yend);
+    color[3] = wu_rfpart(yend) * xgap;
+    if (steep) rasterize_point(o, ypxl1, xpxl1, color); else rasterize_point(o, xpxl1, ypxl1, color);
+    color[3] = wu_fpart(yend) * xgap;
+    if (steep) rasterize_point(o, ypxl1 + 1, xpxl1, color); else rasterize_point(o, xpxl1, ypxl1 + 1, color);
+    float intery = yend + gradient;
+    /* second end point */
+    xend = roundf(x1);
+    yend = y1 + gradient * (xend - x1);
+    xgap = wu_fpart(x1 + 0.5f);
+    const float xpxl2 = xend, ypxl2 = wu_ipart(yend);
+    color[3] = wu_rfpart(yend) * xgap;
+    if (steep) rasterize_point(o, ypxl2, xpxl2, color); else rasterize_point(o, xpxl2, ypxl2, color);
+    color[3] = wu_fpart(yend) * xgap;
+    if (steep) rasterize_point(o, ypxl2 + 1, xpxl2, color); else rasterize_point(o, xpxl2, ypxl2 + 1, color);
+    /* main loop */
+    const float first = xpxl1 + 1, last = xpxl2 - (float)o->sr;
+    if (first <= last && !(first > -16777216.0f && last < 16777216.0f)) return -1;
+    for (float x = first; x <= last; ++x) {
+        color[3] = wu_rfpart(intery);
+        if (steep) rasterize_point(o, wu_ipart(intery), x, color); else rasterize_point(o, x, wu_ipart(intery), color);
+        color[3] = wu_fpart(intery);
+        if (steep) rasterize_point(o, wu_ipart(intery) + 1, x, color); else rasterize_point(o, x, wu_ipart(intery) + 1, color);
+        intery += gradient;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * Images: rasterize_image (software_renderer.cpp:540-570) + Sampler2DImp (texture.cpp:53-193).
  * A texture is a mip chain of RGBA8 levels.  Reads past the end of a level's texel vector (the reference
@@ -320,6 +368,7 @@ int srt_oracle_raster_frame_tex(const srt_prim* prims, size_t n, uint32_t w, uin
         const srt_prim* p = &prims[i];
         if (p->kind == SRT_PRIM_TRIANGLE) rasterize_triangle(&o, p->v.tri, p->rgba);
         else if (p->kind == SRT_PRIM_POINT) rasterize_point(&o, p->v.point[0], p->v.point[1], p->rgba);
+        else if (p->kind == SRT_PRIM_LINE) rc = rasterize_line(&o, p->v.tri[0], p->v.tri[1], p->v.tri[2], p->v.tri[3], p->rgba);
         else if (p->kind == SRT_PRIM_IMAGE && p->reserved < ntex)
             rc = rasterize_image(&o, p->v.tri[0], p->v.tri[1], p->v.tri[2], p->v.tri[3], &tex[p->reserved]);
         else rc = -1;

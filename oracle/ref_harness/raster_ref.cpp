@@ -135,7 +135,7 @@ long ref_raster_svg_textures(const char* path, uint32_t w, uint32_t h, uint32_t 
   return (long)tex.size();
 }
 
-// Feed a primitive stream straight into the reference's private rasterize_triangle / rasterize_point,
+// Feed a primitive stream straight into the reference's private rasterize_triangle / rasterize_line / rasterize_point / rasterize_image,
 // then resolve.  This is the call sequence draw_svg makes, minus the SVG walk.
 int ref_raster_prims_tex(const srt_prim* prims, size_t n, uint32_t w, uint32_t h, uint32_t sr, uint32_t ntex,
                          const uint32_t* tex_nlevels, const uint32_t* level_w, const uint32_t* level_h,
@@ -165,6 +165,8 @@ int ref_raster_prims_tex(const srt_prim* prims, size_t n, uint32_t w, uint32_t h
       ren->rasterize_triangle(p.v.tri[0], p.v.tri[1], p.v.tri[2], p.v.tri[3], p.v.tri[4], p.v.tri[5], c);
     else if (p.kind == SRT_PRIM_POINT)
       ren->rasterize_point(p.v.point[0], p.v.point[1], c);
+    else if (p.kind == SRT_PRIM_LINE)
+      ren->rasterize_line(p.v.tri[0], p.v.tri[1], p.v.tri[2], p.v.tri[3], c);   // = rasterize_line_xiaolinwu (cpp:303-318)
     else if (p.kind == SRT_PRIM_IMAGE && p.reserved < ntex)
       ren->rasterize_image(p.v.tri[0], p.v.tri[1], p.v.tri[2], p.v.tri[3], textures[p.reserved]);
     else

@@ -38,6 +38,7 @@ PRIM_DTYPE = np.dtype(
 PRIM_TRIANGLE = 1
 PRIM_POINT = 2
 PRIM_IMAGE = 3
+PRIM_LINE = 4
 
 
 class SrtError(RuntimeError):
@@ -92,6 +93,8 @@ def load_library() -> ctypes.CDLL:
     lib.srt_raster_read_samples.argtypes = [c_void_p, c_void_p]
     lib.srt_raster_stats.argtypes = [c_void_p, POINTER(RasterStats)]
     lib.srt_raster_sync.argtypes = [c_void_p]
+    lib.srt_raster_bind_output.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.srt_raster_invalidate.argtypes = [c_void_p]
     _bind_pathtracer(lib)
     _lib = lib
     return lib
@@ -164,6 +167,7 @@ class SoftwareRenderer:
 
     def close(self) -> None:
         if self._ctx:
+            self._lib.srt_raster_bind_output(self._ctx, None, 0)   # unpin while the framebuffer is still alive
             self._lib.srt_raster_destroy(self._ctx)
             self._ctx = c_void_p()
 
@@ -187,6 +191,11 @@ class SoftwareRenderer:
         self.render_target = render_target
         self.target_w, self.target_h = int(width), int(height)
         _check(self._lib, self._lib.srt_raster_set_target(self._ctx, self.target_w, self.target_h, self.sample_rate))
+        # the lent framebuffer is pinned once (as the C++ drop-in does in set_render_target): read-backs are one DMA transfer
+        if render_target is not None and render_target.flags.c_contiguous:
+            _check(self._lib, self._lib.srt_raster_bind_output(self._ctx, render_target.ctypes.data_as(c_void_p), render_target.nbytes))
+        else:
+            _check(self._lib, self._lib.srt_raster_bind_output(self._ctx, None, 0))
 
     def clear_target(self) -> None:
         if self.render_target is not None:
@@ -235,6 +244,10 @@ class SoftwareRenderer:
         ptr = c_void_p()
         _check(self._lib, self._lib.srt_raster_resolve_device(self._ctx, c_void_p(stream), ctypes.byref(ptr)))
         return ptr.value
+
+    def invalidate(self) -> None:
+        """The next frame derives bounding boxes, line tables and bin lists again (a full frame of a resident stream)."""
+        _check(self._lib, self._lib.srt_raster_invalidate(self._ctx))
 
     def read_samples(self) -> np.ndarray:
         sr = self.sample_rate

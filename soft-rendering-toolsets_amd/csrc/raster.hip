@@ -6,16 +6,19 @@
 //   inside_triangle     software_renderer.cpp:519-538   fp64 edge functions rounded to fp32, fp32 sign products
 //   fill_sample         software_renderer.cpp:634-658   non-premultiplied "over" on a float RGBA sample in [0,255]
 //   rasterize_point     software_renderer.cpp:272-301   sr x sr block, double -> int truncation
+//   rasterize_line      software_renderer.cpp:303-318   = rasterize_line_xiaolinwu :365-454: float end point / gradient math,
+//                                                       the serial `intery += gradient` chain, its rasterize_point calls
 //   rasterize_image     software_renderer.cpp:540-570   float x/y loops, fp64 u/v, Sampler2DImp::sample_trilinear
 //   sample_bilinear     texture.cpp:145-169             4 texels of one mip level, lerpColor in fp32
 //   resolve             software_renderer.cpp:573-622   fp32 box sum (x-offset outer, y-offset inner), /sr^2, (uint8_t)
 //
 // Execution model: one wavefront (64 lanes) owns one tile of at most 32x32 samples.  The supersample
 // buffer of the reference (16 B/sample, 256 MiB at 1024^2 x 16 spp) is never materialised in HBM: a
-// tile lives in 16 KiB of LDS from clear to resolve, and only 4 B/pixel leave the CU.  The wave walks
-// the frame's primitive stream IN ORDER (painter's algorithm is order dependent), 64 bounding boxes
-// per step, and rasterizes the overlapping ones into its tile: lane = (x = lane & 31, row parity =
-// lane >> 5), two sample rows per iteration.
+// tile lives in the wave's REGISTERS from clear to resolve - lane = (column lane & 31, row parity lane >> 5)
+// owns the samples of its column in every other row, TSY / 2 float4 values with static indices - passes
+// through LDS once, for the box filter, and only 4 B/pixel leave the CU.  The wave walks its bin's
+// primitive list IN ORDER (painter's algorithm is order dependent), 64 bounding boxes per step, and
+// rasterizes the overlapping ones into its tile.
 //
 // Numerics: compiled with -ffp-contract=off (the x86-64 reference build has no FMA), IEEE fp32
 // division (hipcc default) and fp32 denormals preserved, so every coverage verdict and every blended
@@ -71,6 +74,27 @@ struct ImageAux {
   int32_t bx0, by0, bx1, by1;   // inclusive sample bbox of the filled columns / rows (bx0 > bx1: touches nothing)
 };
 
+// One SRT_PRIM_LINE record after raster_setup: rasterize_line_xiaolinwu's end points and main loop in the form the tile
+// kernel needs.  Coordinates are pixels (the arguments of the reference's rasterize_point calls), kept as the reference's
+// floats; (major, minor) = (x, y), or (y, x) for a steep line.  The main loop's serial `intery += gradient` chain is run
+// once, by the setup thread of the line, into a table: entry k - k0 = intery at step k, for the steps whose major
+// coordinate lies inside the target (k0 .. kmax).
+struct LineAux {
+  float e_major[2], e_minor[2];   // end point 1, 2: (xpxl, ypxl)
+  float e_top[2], e_bot[2];       // coverage of pixel (xpxl, ypxl) and of (xpxl, ypxl + 1)
+  int32_t first;                  // major coordinate of step 0 (xpxl1 + 1; integer-valued, |.| < 2^24 wherever steps exist)
+  int32_t k0, kmax;               // steps with a table entry (kmax < k0: none)
+  uint32_t tab;                   // offset of step k0's entry in the table
+  uint32_t steep;
+  uint32_t pad[3];
+};
+static_assert(sizeof(LineAux) == 64, "LineAux is read with scalar loads, 64 bytes");
+
+// Device words a frame reports back (copied to the host with the image): what the line tables and the packed bin lists
+// needed (the host grows the buffers and repeats the frame when they did not fit), refusals.
+enum { FS_TABLE_NEED = 0, FS_LIST_NEED, FS_FLAGS, FS_COUNT };
+constexpr uint32_t kFlagLineUnwalkable = 1u;   // a line whose main loop the reference's `++x` on a float could not walk
+
 // stats slots (unsigned long long each)
 enum { ST_TESTS_REF = 0, ST_TESTS_TARGET, ST_FRAGMENTS, ST_POINT_SAMPLES, ST_BIN_ENTRIES, ST_COUNT };
 
@@ -93,11 +117,108 @@ __device__ __forceinline__ float4 blend_over(float4 s, float r, float g, float b
 // Pass 1: per-primitive sample-space bounding box clipped to the target, int4 {x0,y0,x1,y1}
 // (inclusive; x0 > x1 marks "touches nothing").  Also the reference's own (unclipped) test count.
 // ---------------------------------------------------------------------------------------------
+// ipart / fpart / rfpart, software_renderer.cpp:355-363 (float in, float out)
+__device__ __forceinline__ float wu_ipart(float x) { return floorf(x); }
+__device__ __forceinline__ float wu_fpart(float x) { return x - floorf(x); }
+__device__ __forceinline__ float wu_rfpart(float x) { return 1 - wu_fpart(x); }
+
+// rasterize_line_xiaolinwu (software_renderer.cpp:365-454) for one LINE record: everything but the fills.  Writes the record's
+// LineAux and its slice of the intery table (reserved with one atomic on status[FS_TABLE_NEED]; a slice that does not fit is
+// not written - the host sees the need, grows the table and repeats the frame) and returns the clipped sample-space bounding
+// box of the pixels the line's rasterize_point calls touch.
+__device__ int4 setup_line(const RasterParams& P, const srt_prim& p, LineAux* __restrict__ out, float* __restrict__ table,
+                           uint32_t table_cap, uint32_t* __restrict__ status) {
+  float x0 = p.v.tri[0], y0 = p.v.tri[1], x1 = p.v.tri[2], y1 = p.v.tri[3];
+  const bool steep = fabsf(x1 - x0) < fabsf(y1 - y0);
+  if (steep) { float t = x0; x0 = y0; y0 = t; t = x1; x1 = y1; y1 = t; }
+  if (x0 > x1) { float t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float gradient = (dx == 0.0f) ? 1.0f : dy / dx;
+  LineAux A;
+  A.steep = steep ? 1u : 0u; A.pad[0] = A.pad[1] = A.pad[2] = 0u;
+  // first end point
+  float xend = roundf(x0);
+  float yend = y0 + gradient * (xend - x0);
+  float xgap = wu_rfpart(x0 + 0.5f);
+  const float xpxl1 = xend, ypxl1 = wu_ipart(yend);
+  A.e_major[0] = xpxl1; A.e_minor[0] = ypxl1; A.e_top[0] = wu_rfpart(yend) * xgap; A.e_bot[0] = wu_fpart(yend) * xgap;
+  float intery = yend + gradient;   // first y-intersection for the main loop
+  // second end point
+  xend = roundf(x1);
+  yend = y1 + gradient * (xend - x1);
+  xgap = wu_fpart(x1 + 0.5f);
+  const float xpxl2 = xend, ypxl2 = wu_ipart(yend);
+  A.e_major[1] = xpxl2; A.e_minor[1] = ypxl2; A.e_top[1] = wu_rfpart(yend) * xgap; A.e_bot[1] = wu_fpart(yend) * xgap;
+  // main loop: for (float x = xpxl1 + 1; x <= xpxl2 - 1 * sample_rate; ++x)
+  const float first = xpxl1 + 1, last = xpxl2 - (float)P.sr;
+  A.first = 0; A.k0 = 0; A.kmax = -1; A.tab = 0;
+  // pixel ranges the fills can touch, in (major, minor); the minor range grows with the steps inside the target
+  float mlo = fminf(ypxl1, ypxl2), mhi = fmaxf(ypxl1 + 1, ypxl2 + 1);   // (NaN operands drop out: a NaN end point fills nothing)
+  if (first <= last) {
+    if (!(first > -16777216.0f && last < 16777216.0f)) atomicOr(&status[FS_FLAGS], kFlagLineUnwalkable);
+    else {
+      // (first, last: integer-valued, |.| < 2^24; the differences need 26 bits: double)
+      const double ext = (double)(steep ? P.h : P.w);                     // major extent of the target, pixels
+      const double ka = first < 0.0f ? -(double)first : 0.0;              // first step with major >= 0
+      const double kb = fmin((double)last - (double)first, ext - 1.0 - (double)first);   // last step with major < ext
+      if (ka <= kb) {
+        A.first = (int32_t)first; A.k0 = (int32_t)ka; A.kmax = (int32_t)kb;
+        const uint32_t n = (uint32_t)(A.kmax - A.k0) + 1u;
+        A.tab = atomicAdd(&status[FS_TABLE_NEED], n);
+        const bool fits = (uint64_t)A.tab + n <= (uint64_t)table_cap;
+        // the reference's serial chain, step by step: first the steps left of / above the target (nothing to keep), then the
+        // steps inside it, four table entries per store
+        for (int32_t k = 0; k < A.k0; k++) intery += gradient;
+        const float ilo = intery;
+        float ihi = intery;
+        float* __restrict__ dst = table + A.tab;
+        uint32_t j = 0;
+        if (fits) {
+          for (; j + 4u <= n; j += 4u) {
+            const float a = intery, b = a + gradient, c = b + gradient, d = c + gradient;
+            dst[j] = a; dst[j + 1] = b; dst[j + 2] = c; dst[j + 3] = d;
+            ihi = d;
+            intery = d + gradient;
+          }
+        }
+        for (; j < n; j++) {
+          if (fits) dst[j] = intery;
+          ihi = intery;
+          intery += gradient;
+        }
+        // (x + g is monotone in the number of steps: the chain's extremes are its ends)
+        mlo = fminf(mlo, wu_ipart(fminf(ilo, ihi))); mhi = fmaxf(mhi, wu_ipart(fmaxf(ilo, ihi)) + 1);
+        if (!fits) A.kmax = A.k0 - 1;
+      }
+    }
+  }
+  *out = A;
+  // bounding box: major [xpxl1, xpxl2] (the steps lie between the end points), minor [mlo, mhi]; pixels -> samples
+  const float Mlo = fminf(xpxl1, xpxl2), Mhi = fmaxf(xpxl1, xpxl2);
+  int4 bb = make_int4(1, 1, 0, 0);
+  if (Mlo == Mlo && mlo == mlo) {
+    const double sr = (double)P.sr;
+    double xlo = (steep ? (double)mlo : (double)Mlo) * sr, xhi = (steep ? (double)mhi : (double)Mhi) * sr + (sr - 1.0);
+    double ylo = (steep ? (double)Mlo : (double)mlo) * sr, yhi = (steep ? (double)Mhi : (double)mhi) * sr + (sr - 1.0);
+    const double wx = (double)(P.ssw - 1), wy = (double)(P.ssh - 1);
+    if (xhi >= 0.0 && xlo <= wx && yhi >= 0.0 && ylo <= wy) {
+      bb.x = (int)(xlo < 0.0 ? 0.0 : xlo); bb.y = (int)(ylo < 0.0 ? 0.0 : ylo);
+      bb.z = (int)(xhi > wx ? wx : xhi);   bb.w = (int)(yhi > wy ? wy : yhi);
+    }
+  }
+  return bb;
+}
+
 __global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims, const ImageAux* __restrict__ aux,
-                             int4* __restrict__ bbox, unsigned long long* __restrict__ stats) {
+                             int4* __restrict__ bbox, unsigned long long* __restrict__ stats, LineAux* __restrict__ laux,
+                             float* __restrict__ ltable, uint32_t ltable_cap, uint32_t* __restrict__ status) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.nprims) return;
   const srt_prim p = prims[i];
+  if (p.kind == SRT_PRIM_LINE) {   // `reserved` of the device copy = ordinal of the record among the stream's lines
+    bbox[i] = setup_line(P, p, laux + p.reserved, ltable, ltable_cap, status);
+    return;
+  }
   int4 bb = make_int4(1, 1, 0, 0);
   double lox, hix, loy, hiy;  // inclusive integer-valued ranges the reference loops over
   bool ok = false;
@@ -166,8 +287,11 @@ __device__ __forceinline__ uint32_t bins_of_super(const RasterParams& P, uint32_
 template <int LEVEL>
 __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const int4* __restrict__ bbox, const uint32_t* __restrict__ in_lists,
                                                          const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_lists,
-                                                         uint32_t* __restrict__ out_counts, uint32_t* __restrict__ offs) {
+                                                         uint32_t* __restrict__ out_counts, uint32_t* __restrict__ offs,
+                                                         uint32_t list_cap, uint32_t* __restrict__ status) {
   __shared__ uint32_t s_base;
+  __shared__ uint32_t s_fits;
+  bool fits = true;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   int x0, y0, x1, y1;
   const uint32_t* __restrict__ in = nullptr;
@@ -188,18 +312,24 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
     ncand = in_counts[sb];
     // where this bin's list starts: room for every earlier super-bin's bins, then this bin's rank inside its super-bin
     if (threadIdx.x < 64) {
-      uint32_t part = 0;
-      for (uint32_t k = (uint32_t)lane; k < sb; k += 64u) part += in_counts[k] * bins_of_super(P, k);
-      for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_down((int)part, off);
+      unsigned long long part = 0;
+      for (uint32_t k = (uint32_t)lane; k < sb; k += 64u) part += (unsigned long long)in_counts[k] * bins_of_super(P, k);
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
       if (lane == 0) {
         const uint32_t bw = min(P.super_bx, P.coarse_x - sxi * P.super_bx);
         const uint32_t local = (cy - syi * P.super_by) * bw + (cx - sxi * P.super_bx);
-        s_base = part + local * ncand;
+        const unsigned long long base = part + (unsigned long long)local * ncand, end = base + ncand;
+        // The lists' storage is the caller's guess (it is kept across frames): a list that would not fit is left empty and the
+        // room the frame needs is reported - the host grows the storage and repeats the frame (status[FS_LIST_NEED])
+        s_fits = end <= (unsigned long long)list_cap ? 1u : 0u;
+        if (!s_fits) atomicMax(&status[FS_LIST_NEED], end > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)end);
+        s_base = s_fits ? (uint32_t)base : 0u;
       }
     }
     __syncthreads();
     out = out_lists + s_base;
     if (threadIdx.x == 0) offs[bin] = s_base;
+    fits = s_fits != 0u;
   }
   // K candidates per thread and step, candidate j * blockDim + thread of the step (coalesced loads; a thread's K loads are
   // independent and in flight together).  A step's order is (j, wave, lane): the hits of (j, wave) are a ballot mask kept in
@@ -211,6 +341,7 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
   __shared__ unsigned long long s_mask[NM];
   __shared__ uint32_t s_pref[NM + 1];
   uint32_t total = 0;
+  if (!fits) ncand = 0;                                  // (a list without room stays empty)
   for (uint32_t base = 0; base < ncand; base += blockDim.x * K) {
     uint32_t mine = 0;
 #pragma unroll
@@ -307,7 +438,18 @@ __device__ __forceinline__ float4 sample_image(const ImageAux& A, const uint8_t*
 // ---------------------------------------------------------------------------------------------
 // TSY: tile height in samples (16: 8 KiB of LDS per tile and twice the waves per CU - the kernel is bound by the
 // latency of a wave's own instruction stream, not by throughput - and tighter culling; 32 for sample rates > 16).
-template <bool STATS, int TSY>
+// IMG: the build for streams with SRT_PRIM_IMAGE records.  The texture sampling (two bilinear look-ups, unrolled over the loop
+// values that fold onto a sample) is two thirds of that build's code and weighs on its register allocation; frames without
+// images - nearly all - run the build without it.
+//
+// The tile stays in LDS.  Round 3 measured the alternative the review asked for - the tile in registers, each lane owning the
+// samples of its column in every other row as TSY / 2 float4 values with static indices, LDS touched only for the resolve -
+// bit-exact on every fixture, and slower: cfg2 0.215 ms per frame against 0.178, the stress frame 8.9 ms against 6.9
+// (DESIGN.md section 1).  These frames are bound by the instructions spent per (primitive, tile) pair and per row pair, not by
+// the fills: the 1000 slivers of the stress frame cover 11.7 M samples of 5.9 G tested, and the unrolled row loops with their
+// per-row range tests, the bookkeeping of which register holds which row and the 15-60 spilled registers cost more than the
+// 2.5 M LDS instructions of a frame.
+template <bool STATS, int TSY, bool IMG>
 // (five waves per SIMD where the tile's LDS leaves room for them - 96 VGPRs, 7 spilled: 8-sample-high tiles at 20 waves per CU
 //  measure 6 % faster on cfg2 than 16-high ones at 16; six and eight waves per SIMD lose to their spills)
 #ifndef SRT_RASTER_OCC
@@ -320,10 +462,17 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
                                                      const uint32_t* __restrict__ offs,
                                                      const ImageAux* __restrict__ aux, const float* __restrict__ tabs,
                                                      const uint8_t* __restrict__ texels,
+                                                     const LineAux* __restrict__ laux, const float* __restrict__ ltable,
                                                      uint32_t* __restrict__ rgba_out,
                                                      float4* __restrict__ samples_out,
-                                                     unsigned long long* __restrict__ stats) {
+                                                     unsigned long long* __restrict__ stats,
+                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ host_status) {
   __shared__ float4 tile[TS * TSY];  // 8 / 16 KiB: the tile's slice of super_sample_buffer
+  // The frame's status words (what setup and binning needed, refusals) go to the host from here: one lane copies them into pinned
+  // host memory and clears them for the next frame - a memset before and a copy after the frame were two more launches of ~5 us.
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < FS_COUNT; k++) { host_status[k] = status[k]; status[k] = 0u; }
+  }
   __shared__ double rowy[TSY];       // y / sample_rate for each tile row (fp64 division done once)
 
   const int lane = threadIdx.x;
@@ -342,6 +491,13 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
   const int lx = lane & (TS - 1);
   const int lrow = lane >> 5;
   const double px = (double)(sx0 + lx) / (double)P.sr;  // x / sample_rate (cpp:510)
+  // Pixel of a sample (lines compare pixels): the tile's origin is a whole pixel (tx * tile_px, ty * tile_py) and the offset inside
+  // the tile is below 32, so floor(o / sr) = (int)((o + 0.5) * (1 / sr)) exactly - (o + 0.5) / sr is at least 1 / 64 away from
+  // every integer, far more than the rounding of the reciprocal and the product - and no integer division is spent on it.
+  const float rsr = 1.0f / (float)P.sr;
+  const int tpx0 = tx * (int)P.tile_px, tpy0 = ty * (int)P.tile_py;           // pixel rectangle of the tile (uniform)
+  const int tpx1 = tpx0 + (int)(((float)(tsw - 1) + 0.5f) * rsr), tpy1 = tpy0 + (int)(((float)(tsh - 1) + 0.5f) * rsr);
+  const int colpix = tpx0 + (int)(((float)lx + 0.5f) * rsr);
   __syncthreads();
 
   unsigned long long n_tests = 0, n_frags = 0, n_pts = 0, n_bins = 0;
@@ -417,7 +573,59 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
           }
           if (STATS) n_frags += __popcll(__ballot(covered));
         }
-      } else if (kind == SRT_PRIM_IMAGE) {
+      } else if (kind == SRT_PRIM_LINE) {
+        // rasterize_line_xiaolinwu's fills (raster_setup did the arithmetic), per sample: a fill is one PIXEL - rasterize_point's
+        // sr x sr block at integer coordinates - so a sample takes it iff its pixel is the fill's.  For one sample the reference's
+        // order is: first end point, second end point, main loop (the pixels of different stages can coincide on short lines;
+        // within a stage they are distinct).
+        const LineAux A = laux[__builtin_amdgcn_readlane(q0.y, b)];     // (uniform: scalar loads)
+        const bool steep = A.steep != 0u;
+        const int tM0 = steep ? tpy0 : tpx0, tM1 = steep ? tpy1 : tpx1, tm0 = steep ? tpx0 : tpy0, tm1 = steep ? tpx1 : tpy1;
+        // which stages can touch this tile at all (uniform)
+        bool st_end[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+          st_end[e] = A.e_major[e] >= (float)tM0 && A.e_major[e] <= (float)tM1 && A.e_minor[e] + 1 >= (float)tm0 && A.e_minor[e] <= (float)tm1;   // (false for NaN)
+        bool st_main = false;
+        if (A.kmax >= A.k0) {
+          // main loop: steps ka .. kb cross the tile's major range; intery is monotone in the step (x + g repeated), so the pixels
+          // they fill lie between the two ends' values
+          const int ka = max(tM0 - A.first, A.k0), kb = min(tM1 - A.first, A.kmax);
+          if (ka <= kb) {
+            const float ya = ltable[A.tab + (uint32_t)(ka - A.k0)], yb = ltable[A.tab + (uint32_t)(kb - A.k0)];
+            const float ylo = floorf(fminf(ya, yb)), yhi = floorf(fmaxf(ya, yb)) + 1;
+            st_main = !(yhi < (float)tm0) && !(ylo > (float)tm1);          // (NaN: stays in, fills nothing)
+          }
+        }
+        if (st_end[0] || st_end[1] || st_main) {
+          const bool xin = (lx >= rx0) && (lx <= rx1);
+          for (int row = ry0 + lrow; row <= ry1; row += 2) {
+            const int rp = tpy0 + (int)(((float)row + 0.5f) * rsr);          // pixel row
+            const int Mi = steep ? rp : colpix;
+            const float M = (float)Mi, m = (float)(steep ? colpix : rp);
+            const int si = row * TS + lx;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+              if (st_end[e]) {
+                const float em = A.e_minor[e];                                // rasterize_point(xpxl, ypxl), (xpxl, ypxl + 1)
+                const bool ht = xin && M == A.e_major[e] && m == em, hb = xin && M == A.e_major[e] && m == em + 1;
+                if (ht || hb) tile[si] = blend_over(tile[si], cr, cg, cb, 1 - (ht ? A.e_top[e] : A.e_bot[e]));   // fill_sample's (1 - c.a)
+                if (STATS) n_pts += __popcll(__ballot(ht || hb));
+              }
+            }
+            if (st_main) {
+              const int k = Mi - A.first;
+              const bool in_k = xin && k >= A.k0 && k <= A.kmax;
+              float iy = 0.0f;
+              if (in_k) iy = ltable[A.tab + (uint32_t)(k - A.k0)];
+              const float ip = floorf(iy), fp = iy - ip;                      // ipart, fpart
+              const bool ht = in_k && m == ip, hb = in_k && m == ip + 1;      // rasterize_point(x, ipart), (x, ipart + 1)
+              if (ht || hb) tile[si] = blend_over(tile[si], cr, cg, cb, ht ? 1 - (1 - fp) : 1 - fp);   // 1 - rfpart / 1 - fpart
+              if (STATS) n_pts += __popcll(__ballot(ht || hb));
+            }
+          }
+        }
+      } else if (IMG && kind == SRT_PRIM_IMAGE) {
         // rasterize_image: every (x, y) pair of the float loops whose truncation lands on this lane's sample, x outer
         const ImageAux A = aux[__builtin_amdgcn_readlane(q0.y, b)];
         const int sx = sx0 + lx;
@@ -442,7 +650,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
             }
           }
         }
-      } else {  // SRT_PRIM_POINT
+      } else if (kind == SRT_PRIM_POINT) {
         const uint32_t sr = P.sr;
         const double fx = __hiloint2double((int)w3, (int)w2) * (double)sr;   // v.point[0], v.point[1]
         const double fy = __hiloint2double((int)w5, (int)w4) * (double)sr;
@@ -530,20 +738,34 @@ struct srt_raster {
   hipStream_t stream = nullptr;
   RasterParams P{};
   bool have_target = false;
-  std::vector<srt_prim> pending;  // host copy of the frame's ordered stream
-  bool dirty = true;              // pending differs from d_prims
+  // The frame's ordered stream, in PINNED host memory (grown geometrically): srt_raster_submit appends here and the upload is
+  // one DMA transfer, no staging copy.
+  srt_prim* pending = nullptr; size_t pending_n = 0, pending_cap = 0;
+  std::vector<srt_prim> uploaded;   // what d_prims holds (host copy): an identical resubmission uploads and bins nothing
+  bool dirty = true;                // pending differs from d_prims
+  hipEvent_t upload_done = nullptr; bool upload_pending = false;   // the DMA out of `pending` may still be reading it
   srt_prim* d_prims = nullptr;
   int4* d_bbox = nullptr;
   size_t d_cap = 0;
-  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists, packed (raster_bin_pass<2>)
+  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists, packed (raster_bin_pass<2>); kept across frames and streams
   uint32_t* d_counts = nullptr; size_t counts_cap = 0; // per coarse bin: entries, then (second half) list offsets
   uint32_t* d_super = nullptr; size_t super_cap = 0;   // super-bin lists (<= 64 x nprims) followed by their 64 counts
-  bool bins_dirty = true;                              // stream or target changed: the list storage has to be re-sized
-  size_t list_entries = 0;                             // room the packed bin lists need for the current stream / target
+  bool bins_valid = false;                             // the bin lists on the device belong to the current stream / target / tiling
+  bool verified = false;                               // ... and a frame with them has reported that every buffer was large enough
+  uint32_t coarse_min = 4;                             // tiles per coarse-bin side to start from (raised when the lists get too long)
+  // lines (SRT_PRIM_LINE): one LineAux per record, the intery table (raster_setup)
+  uint32_t nlines = 0;
+  bool has_images = false;                             // the stream on the device holds SRT_PRIM_IMAGE records (the tile kernel's IMG build)
+  LineAux* d_laux = nullptr; size_t laux_cap = 0;
+  float* d_ltable = nullptr; size_t ltable_cap = 0;
+  uint32_t* d_status = nullptr;                        // FS_* words of the frame in flight
+  uint32_t* h_status = nullptr;                        // ... written here (pinned, device-visible) by the tile kernel's first block
+  uint32_t* d_host_status = nullptr;                   // its device address
   uint32_t* d_rgba = nullptr;
   float4* d_samples = nullptr;
   unsigned long long* d_stats = nullptr;
   bool resolved = false;
+  uint8_t* bound_out = nullptr;                        // srt_raster_bind_output: the caller's framebuffer, pinned
   // textures (srt_raster_add_texture): host copies, then one device blob with 4-byte aligned levels
   struct Tex { uint32_t nlevels; uint32_t w[SRT_MAX_MIP_LEVELS], h[SRT_MAX_MIP_LEVELS]; size_t off[SRT_MAX_MIP_LEVELS]; };
   std::vector<Tex> textures;
@@ -556,11 +778,11 @@ struct srt_raster {
 
 namespace {
 
-// Tile height for this frame.  8-sample-high tiles (4 KiB of LDS, 20 waves per CU) win when the primitives are small (cfg2:
-// 0.189 -> 0.178 ms) or the target has too few 16-high tiles to fill the chip (512^2 x 2: 1.46 -> 0.97 ms on the stress SVG);
-// frames of large primitives on a big target double their (primitive, tile) entries with the smaller tiles and are better
-// off with 16 (1024^2 x 4 stress SVG: 6.9 vs 7.6 ms).  Decided on the host from the target size and the mean bounding-box area
-// of a sample of the stream; the image does not depend on it.
+// Tile height for this frame.  8-sample-high tiles (more waves per CU) win when the primitives are small or the target has too
+// few 16-high tiles to fill the chip (512^2 x 2: 1.46 -> 0.97 ms on the stress SVG); frames of large primitives on a big
+// target double their (primitive, tile) entries with the smaller tiles and are better off with 16 (1024^2 x 4 stress SVG:
+// 6.9 vs 7.6 ms).  Decided on the host from the target size and the mean bounding-box area of a sample of the stream; the
+// image does not depend on it.
 uint32_t choose_tile_height(const srt_raster* r) {
   const uint32_t sr = r->P.sr;
   if (sr > 16) return TS;
@@ -568,13 +790,19 @@ uint32_t choose_tile_height(const srt_raster* r) {
   if (const char* e = getenv("SRT_RASTER_TSY")) { const uint32_t v = (uint32_t)atoi(e); if ((v == 8 || v == 16 || v == 32) && sr <= v) return v; }   // experiments
   const uint64_t tiles16 = (uint64_t)r->P.tiles_x * ((r->P.h + 16 / sr - 1) / (16 / sr));
   if (tiles16 < 8192) return 8;
-  const size_t n = r->pending.size();
+  const size_t n = r->pending_n;
   if (n == 0) return 8;
   const size_t step = n > 2048 ? n / 2048 : 1;
   double area = 0.0; size_t seen = 0;
   for (size_t i = 0; i < n; i += step, seen++) {
     const srt_prim& p = r->pending[i];
     if (p.kind == SRT_PRIM_POINT) { area += 1.0; continue; }
+    if (p.kind == SRT_PRIM_LINE) {                         // two pixels wide along its longer extent
+      const float dx = std::fabs(p.v.tri[2] - p.v.tri[0]), dy = std::fabs(p.v.tri[3] - p.v.tri[1]);
+      const float len = dx < dy ? dy : dx;
+      if (len == len) area += 2.0 * std::min((double)len, (double)std::max(r->P.w, r->P.h));
+      continue;
+    }
     float x0 = p.v.tri[0], x1 = p.v.tri[0], y0 = p.v.tri[1], y1 = p.v.tri[1];
     const int nv = p.kind == SRT_PRIM_TRIANGLE ? 3 : 2;
     for (int k = 1; k < nv; k++) { x0 = std::min(x0, p.v.tri[2 * k]); x1 = std::max(x1, p.v.tri[2 * k]); y0 = std::min(y0, p.v.tri[2 * k + 1]); y1 = std::max(y1, p.v.tri[2 * k + 1]); }
@@ -582,11 +810,22 @@ uint32_t choose_tile_height(const srt_raster* r) {
     if (x1 > x0 && y1 > y0) area += (double)(x1 - x0) * (double)(y1 - y0);
   }
   const double mean_samples = area / (double)seen * (double)sr * (double)sr;
-  return mean_samples > 8192.0 ? 16u : 8u;                 // (sixteen 32 x 16 tiles' worth)
+  return mean_samples > 32768.0 ? 16u : 8u;                // (sixty-four 32 x 16 tiles' worth; BASELINE configs[1] - ~9 k samples per
+                                                           //  bounding box - is 9 % faster with 8-high tiles, the stress frame 8 % with 16)
+}
+
+template <typename T>
+int grow(T** buf, size_t* cap, size_t need) {
+  if (*cap >= need && *buf) return SRT_OK;
+  if (*buf) SRT_HIP(hipFree(*buf));
+  *buf = nullptr; *cap = 0;      // a failed allocation below must not leave a capacity behind
+  SRT_HIP(hipMalloc(buf, need * sizeof(T)));
+  *cap = need;
+  return SRT_OK;
 }
 
 int upload_stream(srt_raster* r) {
-  const size_t n = r->pending.size();
+  const size_t n = r->pending_n;
   if (n > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32-1 primitives in one frame");
   {
     const uint32_t tsy = choose_tile_height(r);
@@ -594,8 +833,16 @@ int upload_stream(srt_raster* r) {
       r->P.tile_py = tsy / r->P.sr;
       r->P.tile_sy = r->P.tile_py * r->P.sr;
       r->P.tiles_y = (r->P.h + r->P.tile_py - 1) / r->P.tile_py;
-      r->bins_dirty = true;
+      r->bins_valid = false;
     }
+  }
+  // the same stream again (DrawSVG redraws on every event): nothing to upload, and the bin lists on the device stay valid
+  bool has_image = false;
+  for (size_t i = 0; i < n && !has_image; i++) has_image = r->pending[i].kind == SRT_PRIM_IMAGE;
+  if (!has_image && !r->tex_dirty && n == r->uploaded.size() && r->P.nprims == (uint32_t)n &&
+      (n == 0 || std::memcmp(r->pending, r->uploaded.data(), n * sizeof(srt_prim)) == 0)) {
+    r->dirty = false;
+    return SRT_OK;
   }
   if (n > r->d_cap) {
     if (r->d_prims) SRT_HIP(hipFree(r->d_prims));
@@ -606,18 +853,27 @@ int upload_stream(srt_raster* r) {
     SRT_HIP(hipMalloc(&r->d_bbox, cap * sizeof(int4)));
     r->d_cap = cap;
   }
-  // SRT_PRIM_IMAGE records: per-image constants and loop-value tables (ImageAux); the device copy of the record
-  // carries the index of its ImageAux in `reserved`
+  r->uploaded.clear();                                 // (until the copy below has been issued: d_prims holds nothing known)
+  // SRT_PRIM_IMAGE records: per-image constants and loop-value tables (ImageAux); SRT_PRIM_LINE records: their ordinal.
+  // The device copy of such a record carries the index of its ImageAux / LineAux in `reserved`.
   std::vector<ImageAux> aux;
   std::vector<float> tabs;
   std::vector<std::pair<size_t, uint32_t>> patched;   // (record, original reserved)
   const RasterParams& P = r->P;
   const float qnan = std::numeric_limits<float>::quiet_NaN();
+  uint32_t nlines = 0;
   for (size_t i = 0; i < n; i++) {
     srt_prim& p = r->pending[i];
+    if (p.kind == SRT_PRIM_LINE) {
+      patched.emplace_back(i, p.reserved);
+      p.reserved = nlines++;
+      continue;
+    }
     if (p.kind != SRT_PRIM_IMAGE) continue;
-    if (p.reserved >= r->textures.size())
+    if (p.reserved >= r->textures.size()) {
+      for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;
       return srt::fail(SRT_ERR_INVALID, "primitive %zu refers to texture %u, %zu textures are loaded", i, p.reserved, r->textures.size());
+    }
     const srt_raster::Tex& T = r->textures[p.reserved];
     ImageAux A;
     std::memset(&A, 0, sizeof A);
@@ -648,146 +904,186 @@ int upload_stream(srt_raster* r) {
     tabs.resize(tabs.size() + 2 * (size_t)P.ssw, qnan);
     A.ytab = (uint32_t)tabs.size();
     tabs.resize(tabs.size() + 2 * (size_t)P.ssh, qnan);
-    if (tabs.size() > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "image tables exceed 2^32 entries");
-    A.bx0 = A.by0 = 1; A.bx1 = A.by1 = 0;
-    auto walk = [&](float lo, float hi, uint32_t extent, uint32_t tab, int32_t& b0, int32_t& b1) -> int {
-      bool any = false;
-      uint64_t guard = 0;
-      for (float x = lo; x <= hi; x++) {
-        if (x + 1 == x || ++guard > (1ull << 26)) return -1;       // the reference's loop would never end
-        if (!(x > -2147483648.0f && x < 2147483648.0f)) continue;  // (int)x is INT_MIN on x86: rejected by fill_sample
-        const int sx = (int)x;
-        if (sx < 0 || (uint32_t)sx >= extent) continue;
-        float* e = &tabs[tab + sx];
-        if (e[0] != e[0]) e[0] = x;
-        else if (e[extent] != e[extent]) e[extent] = x;
-        else return -2;
-        if (!any) { b0 = b1 = sx; any = true; }
-        b0 = sx < b0 ? sx : b0; b1 = sx > b1 ? sx : b1;
-      }
-      return any ? 1 : 0;
-    };
-    const int rx = walk(x0, x1, P.ssw, A.xtab, A.bx0, A.bx1);
-    const int ry = walk(y0, y1, P.ssh, A.ytab, A.by0, A.by1);
-    if (rx < 0 || ry < 0)
+    int rx = 0, ry = 0;
+    if (tabs.size() <= 0xFFFFFFFFull) {
+      A.bx0 = A.by0 = 1; A.bx1 = A.by1 = 0;
+      auto walk = [&](float lo, float hi, uint32_t extent, uint32_t tab, int32_t& b0, int32_t& b1) -> int {
+        bool any = false;
+        uint64_t guard = 0;
+        for (float x = lo; x <= hi; x++) {
+          if (x + 1 == x || ++guard > (1ull << 26)) return -1;       // the reference's loop would never end
+          if (!(x > -2147483648.0f && x < 2147483648.0f)) continue;  // (int)x is INT_MIN on x86: rejected by fill_sample
+          const int sx = (int)x;
+          if (sx < 0 || (uint32_t)sx >= extent) continue;
+          float* e = &tabs[tab + sx];
+          if (e[0] != e[0]) e[0] = x;
+          else if (e[extent] != e[extent]) e[extent] = x;
+          else return -2;
+          if (!any) { b0 = b1 = sx; any = true; }
+          b0 = sx < b0 ? sx : b0; b1 = sx > b1 ? sx : b1;
+        }
+        return any ? 1 : 0;
+      };
+      rx = walk(x0, x1, P.ssw, A.xtab, A.bx0, A.bx1);
+      ry = walk(y0, y1, P.ssh, A.ytab, A.by0, A.by1);
+    }
+    if (tabs.size() > 0xFFFFFFFFull || rx < 0 || ry < 0) {
+      for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;
+      if (tabs.size() > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "image tables exceed 2^32 entries");
       return srt::fail(SRT_ERR_UNSUPPORTED, "image primitive %zu: extent (%g, %g)-(%g, %g) samples is outside what the reference's float loops can walk",
                        i, (double)x0, (double)y0, (double)x1, (double)y1);
+    }
     if (rx == 0 || ry == 0) { A.bx0 = A.by0 = 1; A.bx1 = A.by1 = 0; }
     patched.emplace_back(i, p.reserved);
     p.reserved = (uint32_t)aux.size();
     aux.push_back(A);
   }
+  // (an intery table never holds more than one entry per line and pixel column / row of the target)
+  const bool lines_fit = (uint64_t)nlines * std::max(P.w, P.h) < (1ull << 32);
   hipError_t up = hipSuccess;
-  if (n) up = hipMemcpy(r->d_prims, r->pending.data(), n * sizeof(srt_prim), hipMemcpyHostToDevice);
-  for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;   // the host copy keeps texture ids
+  if (n && lines_fit) up = hipMemcpyAsync(r->d_prims, r->pending, n * sizeof(srt_prim), hipMemcpyHostToDevice, r->stream);
+  if (up == hipSuccess && !patched.empty()) up = hipStreamSynchronize(r->stream);   // the records are restored below: the copy must have read them
+  else if (up == hipSuccess && n && lines_fit) { up = hipEventRecord(r->upload_done, r->stream); r->upload_pending = up == hipSuccess; }
+  for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;   // the host copy keeps texture ids / the caller's zeros
   SRT_HIP(up);
+  if (!lines_fit) return srt::fail(SRT_ERR_UNSUPPORTED, "%u lines on a %u x %u target: their tables could exceed 2^32 entries", nlines, P.w, P.h);
+  try { r->uploaded.assign(r->pending, r->pending + n); } catch (...) { r->uploaded.clear(); }   // (without the copy the next frame just uploads again)
+  r->nlines = nlines;
+  r->has_images = !aux.empty();
+  if (nlines) {
+    int st = grow(&r->d_laux, &r->laux_cap, (size_t)nlines + nlines / 2);
+    if (st != SRT_OK) return st;
+  }
   if (!aux.empty()) {
-    if (aux.size() > r->aux_cap) {
-      if (r->d_aux) SRT_HIP(hipFree(r->d_aux));
-      r->d_aux = nullptr; r->aux_cap = 0;      // a failed allocation below must not leave a capacity behind
-      SRT_HIP(hipMalloc(&r->d_aux, aux.size() * sizeof(ImageAux)));
-      r->aux_cap = aux.size();
-    }
-    if (tabs.size() > r->tabs_cap) {
-      if (r->d_tabs) SRT_HIP(hipFree(r->d_tabs));
-      r->d_tabs = nullptr; r->tabs_cap = 0;      // a failed allocation below must not leave a capacity behind
-      SRT_HIP(hipMalloc(&r->d_tabs, tabs.size() * sizeof(float)));
-      r->tabs_cap = tabs.size();
-    }
+    int st;
+    if ((st = grow(&r->d_aux, &r->aux_cap, aux.size())) != SRT_OK || (st = grow(&r->d_tabs, &r->tabs_cap, tabs.size())) != SRT_OK) return st;
     SRT_HIP(hipMemcpy(r->d_aux, aux.data(), aux.size() * sizeof(ImageAux), hipMemcpyHostToDevice));
     SRT_HIP(hipMemcpy(r->d_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice));
     if (r->tex_dirty) {
       const size_t nb = r->texel_blob.size() ? r->texel_blob.size() : 4;
-      if (nb > r->texels_cap) {
-        if (r->d_texels) SRT_HIP(hipFree(r->d_texels));
-        r->d_texels = nullptr; r->texels_cap = 0;      // a failed allocation below must not leave a capacity behind
-        SRT_HIP(hipMalloc(&r->d_texels, nb));
-        r->texels_cap = nb;
-      }
+      if ((st = grow(&r->d_texels, &r->texels_cap, nb)) != SRT_OK) return st;
       if (!r->texel_blob.empty()) SRT_HIP(hipMemcpy(r->d_texels, r->texel_blob.data(), r->texel_blob.size(), hipMemcpyHostToDevice));
-      r->tex_dirty = false;
     }
   }
+  r->tex_dirty = false;
   r->P.nprims = (uint32_t)n;
   r->dirty = false;
-  r->bins_dirty = true;                          // another stream: the packed bin lists are sized on its first frame
+  r->bins_valid = false;                         // another stream: setup and binning run on its first frame
+  r->verified = false;
   return SRT_OK;
 }
 
-// Enqueue setup + tile kernels for the current stream on `s`.
+// The binning grid for `c` tiles per coarse-bin side.
+void set_grid(RasterParams& P, uint32_t c) {
+  P.coarse_tiles = c;
+  P.coarse_x = (P.tiles_x + c - 1) / c;
+  P.coarse_y = (P.tiles_y + c - 1) / c;
+  P.super_bx = (P.coarse_x + 7) / 8; P.super_by = (P.coarse_y + 7) / 8;
+  P.super_x = (P.coarse_x + P.super_bx - 1) / P.super_bx; P.super_y = (P.coarse_y + P.super_by - 1) / P.super_by;
+  P.super_stride = P.nprims ? P.nprims : 1;
+}
+
+// Enqueue one frame of the current stream on `s`: raster_setup + the two ordered binning passes when the lists on the device
+// do not belong to this stream / target yet, then the tile kernel; the frame's status words follow into pinned host memory.
+// Nothing here waits for the device.  The line tables and the packed bin lists live in storage that is kept across frames and
+// sized by what earlier frames needed (a first guess for the very first one): a frame whose needs exceed it leaves the
+// affected lists / tables empty and says so in its status - check_frame() then grows the storage and the caller repeats the frame.
 int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   RasterParams& P = r->P;
   if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
-  if (P.nprims) {
-    const int bs = 256;
-    raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_aux, r->d_bbox,
-                                                                      stats ? r->d_stats : nullptr);
-  }
-  // Ordered binning (raster_bin_pass): coarse bins of c x c tiles under <= 8 x 8 super-bins.  The first frame of a stream
-  // reads the 64 super counts back once to size the packed lists by the entries the frame really has; later frames of the
-  // same stream and target only enqueue.
-  for (uint32_t c = 4;; c *= 2) {
-    P.coarse_tiles = c;
-    P.coarse_x = (P.tiles_x + c - 1) / c;
-    P.coarse_y = (P.tiles_y + c - 1) / c;
-    if ((uint64_t)P.coarse_x * P.coarse_y > 8192 && c < 65536) continue;          // (keeps the bin count bounded on huge targets)
-    P.super_bx = (P.coarse_x + 7) / 8; P.super_by = (P.coarse_y + 7) / 8;
-    P.super_x = (P.coarse_x + P.super_bx - 1) / P.super_bx; P.super_y = (P.coarse_y + P.super_by - 1) / P.super_by;
-    P.super_stride = P.nprims ? P.nprims : 1;
+  if (!r->bins_valid || stats) {
+    uint32_t c = r->coarse_min;
+    for (;; c *= 2) {                                                             // (keeps the bin count bounded on huge targets)
+      set_grid(P, c);
+      if ((uint64_t)P.coarse_x * P.coarse_y > 8192 && c < 65536) continue;
+      break;
+    }
     const size_t nb = (size_t)P.coarse_x * P.coarse_y, ns = (size_t)P.super_x * P.super_y;
-    if (r->counts_cap < 2 * nb) {
-      if (r->d_counts) SRT_HIP(hipFree(r->d_counts));
-      r->d_counts = nullptr; r->counts_cap = 0;      // a failed allocation below must not leave a capacity behind
-      SRT_HIP(hipMalloc(&r->d_counts, 2 * nb * sizeof(uint32_t)));
-      r->counts_cap = 2 * nb;
-      r->bins_dirty = true;
+    int st;
+    if ((st = grow(&r->d_counts, &r->counts_cap, 2 * nb)) != SRT_OK) return st;
+    if ((st = grow(&r->d_super, &r->super_cap, ns * P.super_stride + 64)) != SRT_OK) return st;
+    if (!r->d_lists) {       // first guess: a primitive in most bins of ONE super-bin (what small primitives come to); check_frame() corrects it
+      const size_t guess = (size_t)P.nprims * P.super_bx * P.super_by * 3 / 4 + 65536;
+      if ((st = grow(&r->d_lists, &r->lists_cap, std::min<size_t>(guess, 1ull << 28))) != SRT_OK) return st;
     }
-    if (r->super_cap < ns * P.super_stride + 64) {
-      if (r->d_super) SRT_HIP(hipFree(r->d_super));
-      r->d_super = nullptr; r->super_cap = 0;
-      SRT_HIP(hipMalloc(&r->d_super, (ns * P.super_stride + 64) * sizeof(uint32_t)));
-      r->super_cap = ns * P.super_stride + 64;
-      r->bins_dirty = true;
+    if (r->nlines && !r->d_ltable) {
+      if ((st = grow(&r->d_ltable, &r->ltable_cap, (size_t)r->nlines * 64 + 4096)) != SRT_OK) return st;
     }
+    if (P.nprims) {
+      const int bs = 256;
+      raster_setup<<<dim3((P.nprims + bs - 1) / bs), dim3(bs), 0, s>>>(P, r->d_prims, r->d_aux, r->d_bbox, stats ? r->d_stats : nullptr,
+                                                                      r->d_laux, r->d_ltable, (uint32_t)std::min<size_t>(r->ltable_cap, 0xFFFFFFFFull), r->d_status);
+    }
+    // Ordered binning (raster_bin_pass): coarse bins of c x c tiles under <= 8 x 8 super-bins
     uint32_t* d_super_counts = r->d_super + ns * P.super_stride;
-    raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr);
-    if (r->bins_dirty) {
-      uint32_t h_counts[64];
-      SRT_HIP(hipMemcpyAsync(h_counts, d_super_counts, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      SRT_HIP(hipStreamSynchronize(s));
-      uint64_t need = 0;
-      for (uint32_t k = 0; k < ns; k++) {
-        const uint32_t sx = k % P.super_x, sy = k / P.super_x;
-        const uint64_t bw = std::min<uint32_t>(P.super_bx, P.coarse_x - sx * P.super_bx), bh = std::min<uint32_t>(P.super_by, P.coarse_y - sy * P.super_by);
-        need += (uint64_t)h_counts[k] * bw * bh;
-      }
-      if (need > (256ull << 20) && c < 65536) continue;                           // more than 1 GiB of lists: coarser bins
-      if (need >= (1ull << 32)) return srt::fail(SRT_ERR_UNSUPPORTED, "the frame's bin lists need %llu entries", (unsigned long long)need);
-      if (r->lists_cap < need + 1) {
-        if (r->d_lists) SRT_HIP(hipFree(r->d_lists));
-        r->d_lists = nullptr; r->lists_cap = 0;      // a failed allocation below must not leave a capacity behind
-        SRT_HIP(hipMalloc(&r->d_lists, (need + 1) * sizeof(uint32_t)));
-        r->lists_cap = need + 1;
-      }
-      r->list_entries = need;
-      r->bins_dirty = false;
-    }
-    raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, r->d_lists, r->d_counts, r->d_counts + nb);
-    break;
+    raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr, 0u, r->d_status);
+    raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, r->d_lists, r->d_counts, r->d_counts + nb,
+                                                                (uint32_t)std::min<size_t>(r->lists_cap, 0xFFFFFFFFull), r->d_status);
+    r->bins_valid = true;
   }
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
-#define SRT_TILES(STATS_, TSY_, ST_)                                                                                       \
-  raster_tiles<STATS_, TSY_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts,             \
+#define SRT_TILES2(STATS_, TSY_, IMG_, ST_)                                                                                 \
+  raster_tiles<STATS_, TSY_, IMG_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts,       \
                                                                  r->d_counts + (size_t)P.coarse_x * P.coarse_y, r->d_aux,       \
-                                                                 r->d_tabs, r->d_texels, r->d_rgba, so, ST_)
+                                                                 r->d_tabs, r->d_texels, r->d_laux, r->d_ltable, r->d_rgba, so, ST_, r->d_status, r->d_host_status)
+#define SRT_TILES(STATS_, TSY_, ST_) do { if (r->has_images) SRT_TILES2(STATS_, TSY_, true, ST_); else SRT_TILES2(STATS_, TSY_, false, ST_); } while (0)
   const int tsy = P.tile_sy > 16 ? 32 : (P.tile_sy > 8 ? 16 : 8);
   if (stats) { if (tsy == 32) SRT_TILES(true, 32, r->d_stats); else if (tsy == 16) SRT_TILES(true, 16, r->d_stats); else SRT_TILES(true, 8, r->d_stats); }
   else { if (tsy == 32) SRT_TILES(false, 32, nullptr); else if (tsy == 16) SRT_TILES(false, 16, nullptr); else SRT_TILES(false, 8, nullptr); }
 #undef SRT_TILES
+#undef SRT_TILES2
   SRT_HIP(hipGetLastError());
   r->resolved = true;
   return SRT_OK;
+}
+
+// After the stream `s` has been synchronised: did the last setup / binning fit its storage?  Returns 1 when the frame has to
+// be repeated (storage grown, bins invalidated), 0 when the frame is good, < 0 on refusal / failure.
+int check_frame(srt_raster* r) {
+  if (r->verified) return 0;
+  const volatile uint32_t* hs = r->h_status;
+  const uint32_t table_need = hs[FS_TABLE_NEED], list_need = hs[FS_LIST_NEED], flags = hs[FS_FLAGS];
+  if (flags & kFlagLineUnwalkable)
+    return srt::fail(SRT_ERR_UNSUPPORTED, "a line's main loop runs over coordinates beyond 2^24, where the reference's `++x` on a float no longer advances");
+  bool again = false;
+  if (table_need > r->ltable_cap) {
+    const int st = grow(&r->d_ltable, &r->ltable_cap, (size_t)table_need + table_need / 4 + 1024);
+    if (st != SRT_OK) return st;
+    again = true;
+  }
+  if (list_need != 0u) {                           // (reported only by lists that did not fit)
+    if (list_need == 0xFFFFFFFFu || list_need > (256u << 20)) {        // more than 1 GiB of lists: coarser bins
+      if (r->coarse_min >= 65536) return srt::fail(SRT_ERR_UNSUPPORTED, "the frame's bin lists need more than 2^32 entries");
+      r->coarse_min *= 2;
+    } else {
+      const int st = grow(&r->d_lists, &r->lists_cap, (size_t)list_need + list_need / 8 + 1024);
+      if (st != SRT_OK) return st;
+    }
+    again = true;
+  }
+  if (again) { r->bins_valid = false; return 1; }
+  r->verified = true;
+  return 0;
+}
+
+// One frame, repeated while its storage has to grow (at most a few times, and only on the first frame of a stream that needs
+// more than every frame before it).  `sync_all`: the caller needs the frame complete on return; otherwise the function only
+// waits when the stream is new (its needs are unknown until a frame has reported them).
+int run_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats, bool sync_all) {
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int st = launch_frame(r, s, dump_samples, stats);
+    if (st != SRT_OK) return st;
+    if (r->verified && !sync_all) return SRT_OK;
+    if (!r->verified) {
+      SRT_HIP(hipStreamSynchronize(s));
+      st = check_frame(r);
+      if (st < 0) return st;
+      if (st == 1) continue;
+    }
+    return SRT_OK;
+  }
+  return srt::fail(SRT_ERR_STATE, "the frame's buffers kept growing");
 }
 
 }  // namespace
@@ -811,10 +1107,22 @@ int srt_raster_create(int device, srt_raster** out) {
     delete r;
     return srt::fail(SRT_ERR_HIP, "hipStreamCreate failed");
   }
-  if (hipMalloc(&r->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMalloc(&r->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&r->d_status, FS_COUNT * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(r->d_status, 0, FS_COUNT * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc((void**)&r->h_status, FS_COUNT * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&r->d_host_status, r->h_status, 0) != hipSuccess) {
+    (void)hipFree(r->d_stats); (void)hipFree(r->d_status);
     (void)hipStreamDestroy(r->stream);
     delete r;
     return srt::fail(SRT_ERR_HIP, "hipMalloc(stats) failed");
+  }
+  std::memset(r->h_status, 0, FS_COUNT * sizeof(uint32_t));
+  if (hipEventCreateWithFlags(&r->upload_done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipFree(r->d_stats); (void)hipFree(r->d_status); (void)hipHostFree(r->h_status);
+    (void)hipStreamDestroy(r->stream);
+    delete r;
+    return srt::fail(SRT_ERR_HIP, "hipEventCreate failed");
   }
   *out = r;
   return SRT_OK;
@@ -824,6 +1132,7 @@ int srt_raster_destroy(srt_raster* r) {
   if (!r) return SRT_OK;
   (void)hipSetDevice(r->device);
   (void)hipStreamSynchronize(r->stream);
+  if (r->bound_out) (void)hipHostUnregister(r->bound_out);
   (void)hipFree(r->d_prims);
   (void)hipFree(r->d_bbox);
   (void)hipFree(r->d_lists);
@@ -832,10 +1141,17 @@ int srt_raster_destroy(srt_raster* r) {
   (void)hipFree(r->d_rgba);
   (void)hipFree(r->d_samples);
   (void)hipFree(r->d_stats);
+  (void)hipFree(r->d_status);
   (void)hipFree(r->d_texels);
   (void)hipFree(r->d_aux);
   (void)hipFree(r->d_tabs);
+  (void)hipFree(r->d_laux);
+  (void)hipFree(r->d_ltable);
+  if (r->h_status) (void)hipHostFree(r->h_status);
+  if (r->pending) (void)hipHostFree(r->pending);
+  if (r->upload_done) (void)hipEventDestroy(r->upload_done);
   (void)hipStreamDestroy(r->stream);
+  (void)hipGetLastError();
   delete r;
   return SRT_OK;
 }
@@ -867,6 +1183,7 @@ int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widt
 
 int srt_raster_clear_textures(srt_raster* r) {
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear_textures: NULL context");
+  if (r->textures.empty()) return SRT_OK;        // (DrawSVG's redraw clears and re-adds the textures of every frame: nothing to forget here)
   r->textures.clear();
   r->texel_blob.clear();
   r->tex_dirty = true;
@@ -903,13 +1220,17 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   if (r->d_samples) { SRT_HIP(hipFree(r->d_samples)); r->d_samples = nullptr; }
   r->have_target = true;
   r->resolved = false;
-  r->bins_dirty = true;                          // another tiling: the packed bin lists are re-sized on the next frame
+  r->bins_valid = false;                         // another tiling: setup (the lines' tables follow the target) and binning run again
+  r->verified = false;
+  r->coarse_min = 4;
+  r->dirty = true;                               // (image records carry per-target tables)
   return SRT_OK;
 }
 
 int srt_raster_clear(srt_raster* r) {
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear: NULL context");
-  r->pending.clear();
+  if (r->upload_pending) { SRT_HIP(hipEventSynchronize(r->upload_done)); r->upload_pending = false; }   // (the pinned stream buffer is about to be rewritten)
+  r->pending_n = 0;
   r->dirty = true;
   r->resolved = false;
   return SRT_OK;
@@ -920,14 +1241,42 @@ int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n) {
   if (n && !prims) return srt::fail(SRT_ERR_INVALID, "srt_raster_submit: prims is NULL");
   if (!r->have_target) return srt::fail(SRT_ERR_STATE, "srt_raster_submit before srt_raster_set_target");
   for (size_t i = 0; i < n; i++)
-    if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT && prims[i].kind != SRT_PRIM_IMAGE)
+    if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT && prims[i].kind != SRT_PRIM_IMAGE && prims[i].kind != SRT_PRIM_LINE)
       return srt::fail(SRT_ERR_INVALID, "primitive %zu has unknown kind %u", i, prims[i].kind);
-  try {
-    r->pending.insert(r->pending.end(), prims, prims + n);
-  } catch (...) {
-    return srt::fail(SRT_ERR_INVALID, "out of host memory");
+  if (r->upload_pending) { SRT_HIP(hipEventSynchronize(r->upload_done)); r->upload_pending = false; }
+  if (r->pending_n + n > r->pending_cap) {
+    SRT_HIP(hipSetDevice(r->device));
+    SRT_HIP(hipStreamSynchronize(r->stream));      // (an upload may still be reading the old buffer)
+    size_t cap = (r->pending_n + n) * 2 + 1024;
+    srt_prim* grown = nullptr;
+    if (hipHostMalloc((void**)&grown, cap * sizeof(srt_prim), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return srt::fail(SRT_ERR_INVALID, "out of pinned host memory for %zu primitives", cap);
+    }
+    if (r->pending_n) std::memcpy(grown, r->pending, r->pending_n * sizeof(srt_prim));
+    if (r->pending) (void)hipHostFree(r->pending);
+    r->pending = grown; r->pending_cap = cap;
   }
+  if (n) std::memcpy(r->pending + r->pending_n, prims, n * sizeof(srt_prim));
+  r->pending_n += n;
   r->dirty = true;
+  return SRT_OK;
+}
+
+int srt_raster_bind_output(srt_raster* r, uint8_t* host_rgba8, size_t bytes) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_bind_output: NULL context");
+  SRT_HIP(hipSetDevice(r->device));
+  SRT_HIP(hipStreamSynchronize(r->stream));
+  if (r->bound_out) {
+    if (hipHostUnregister(r->bound_out) != hipSuccess) (void)hipGetLastError();   // (the memory may be gone already: nothing to undo then)
+    r->bound_out = nullptr;
+  }
+  if (!host_rgba8 || !bytes) return SRT_OK;
+  if (hipHostRegister(host_rgba8, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();                       // not fatal: srt_raster_resolve works with pageable memory as well
+    return SRT_OK;
+  }
+  r->bound_out = host_rgba8;
   return SRT_OK;
 }
 
@@ -941,7 +1290,7 @@ int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgb
     if (st != SRT_OK) return st;
     if (s != r->stream) SRT_HIP(hipStreamSynchronize(r->stream));  // upload went on the context stream
   }
-  int st = launch_frame(r, s, false, false);
+  int st = run_frame(r, s, false, false, false);
   if (st != SRT_OK) return st;
   if (d_rgba8_out) *d_rgba8_out = (const uint8_t*)r->d_rgba;
   return SRT_OK;
@@ -950,11 +1299,20 @@ int srt_raster_resolve_device(srt_raster* r, void* stream, const uint8_t** d_rgb
 int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out) {
   if (!rgba8_out) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve: output buffer is NULL");
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_resolve: NULL context");
-  int st = srt_raster_resolve_device(r, (void*)r->stream, nullptr);
-  if (st != SRT_OK) return st;
-  SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));
-  SRT_HIP(hipStreamSynchronize(r->stream));
-  return SRT_OK;
+  if (!r->have_target) return srt::fail(SRT_ERR_STATE, "resolve before srt_raster_set_target");
+  SRT_HIP(hipSetDevice(r->device));
+  if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
+  // frame and read-back are enqueued together; one wait.  (A frame whose storage has to grow is repeated: run_frame.)
+  for (int attempt = 0; attempt < 8; attempt++) {
+    int st = launch_frame(r, r->stream, false, false);
+    if (st != SRT_OK) return st;
+    SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));
+    SRT_HIP(hipStreamSynchronize(r->stream));
+    st = check_frame(r);
+    if (st < 0) return st;
+    if (st == 0) return SRT_OK;
+  }
+  return srt::fail(SRT_ERR_STATE, "the frame's buffers kept growing");
 }
 
 int srt_raster_read_samples(srt_raster* r, float* samples_out) {
@@ -964,7 +1322,7 @@ int srt_raster_read_samples(srt_raster* r, float* samples_out) {
   const size_t bytes = (size_t)r->P.ssw * r->P.ssh * sizeof(float4);
   if (!r->d_samples) SRT_HIP(hipMalloc(&r->d_samples, bytes));
   if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
-  int st = launch_frame(r, r->stream, true, false);
+  int st = run_frame(r, r->stream, true, false, true);
   if (st != SRT_OK) return st;
   SRT_HIP(hipMemcpyAsync(samples_out, r->d_samples, bytes, hipMemcpyDeviceToHost, r->stream));
   SRT_HIP(hipStreamSynchronize(r->stream));
@@ -976,7 +1334,8 @@ int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out) {
   if (!r->have_target) return srt::fail(SRT_ERR_STATE, "stats before srt_raster_set_target");
   SRT_HIP(hipSetDevice(r->device));
   if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
-  int st = launch_frame(r, r->stream, false, true);
+  r->verified = false;                           // (the stats pass runs setup and binning again: its status is checked)
+  int st = run_frame(r, r->stream, false, true, true);
   if (st != SRT_OK) return st;
   unsigned long long h[ST_COUNT];
   SRT_HIP(hipMemcpyAsync(h, r->d_stats, sizeof h, hipMemcpyDeviceToHost, r->stream));
@@ -987,6 +1346,12 @@ int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out) {
   out->point_samples = h[ST_POINT_SAMPLES];
   out->bin_entries = h[ST_BIN_ENTRIES];
   out->list_bytes = (uint64_t)(r->super_cap + r->lists_cap + r->counts_cap) * sizeof(uint32_t);
+  return SRT_OK;
+}
+
+int srt_raster_invalidate(srt_raster* r) {
+  if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_invalidate: NULL context");
+  r->bins_valid = false;       // (`verified` stays: the storage has proven large enough for this stream)
   return SRT_OK;
 }
 

@@ -27,7 +27,10 @@ SoftwareRendererHIP::SoftwareRendererHIP(int device) : SoftwareRenderer(), ctx_(
 }
 
 SoftwareRendererHIP::~SoftwareRendererHIP() {
-  if (ctx_) srt_raster_destroy(ctx_);
+  if (ctx_) {
+    srt_raster_bind_output(ctx_, nullptr, 0);   // unpin DrawSVG's framebuffer while it is still alive
+    srt_raster_destroy(ctx_);
+  }
 }
 
 void SoftwareRendererHIP::set_sample_rate(size_t rate) {
@@ -42,9 +45,13 @@ void SoftwareRendererHIP::set_render_target(unsigned char* target_buffer, size_t
   render_target = target_buffer;
   target_w = width;
   target_h = height;
-  if (ctx_)
+  if (ctx_) {
     die_on(srt_raster_set_target(ctx_, (uint32_t)width, (uint32_t)height, (uint32_t)sample_rate),
            "srt_raster_set_target");
+    // DrawSVG lends ONE framebuffer per window size (drawsvg.cpp:107-114): pin it, so that every frame's read-back is one DMA
+    // transfer.  (Binding drops the previous buffer's registration; DrawSVG::resize has already resized the vector by now.)
+    die_on(srt_raster_bind_output(ctx_, target_buffer, 4 * width * height), "srt_raster_bind_output");
+  }
 }
 
 void SoftwareRendererHIP::clear_target() {
@@ -57,7 +64,9 @@ void SoftwareRendererHIP::draw_svg(SVG& svg) {
     std::fprintf(stderr, "[SoftwareRendererHIP] draw_svg without a device context; there is no CPU path\n");
     std::abort();
   }
-  clear_target();
+  // SoftwareRendererImp::draw_svg starts with clear_target() (cpp:19); the render target's part of it - a 4 MiB memset at
+  // 1024^2 - is skipped here because srt_raster_resolve below writes every byte of it
+  die_on(srt_raster_clear(ctx_), "srt_raster_clear");
   const std::vector<srt_prim>& stream = builder_.build(svg, svg_2_screen, sample_rate);
   // <image> textures: the mip chains DrawSVG::regenerate_mipmap built with the application's sampler
   die_on(srt_raster_clear_textures(ctx_), "srt_raster_clear_textures");

@@ -9,8 +9,8 @@
 //
 // Split of work:
 //   host  : element walk, transform stack, ear-clip triangulation (the reference's own
-//           triangulate()), Xiaolin-Wu line decomposition into rasterize_point blocks (svg_stream.cpp)
-//   device: rasterize_triangle + inside_triangle + fill_sample + rasterize_point + rasterize_image
+//           triangulate()) (svg_stream.cpp)
+//   device: rasterize_triangle + inside_triangle + fill_sample + rasterize_line_xiaolinwu + rasterize_point + rasterize_image
 //           (Sampler2DImp::sample_trilinear over the application's mip chains) + resolve
 #ifndef SRT_SOFTWARE_RENDERER_HIP_H
 #define SRT_SOFTWARE_RENDERER_HIP_H

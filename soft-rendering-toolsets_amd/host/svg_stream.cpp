@@ -1,10 +1,10 @@
 // See svg_stream.h. Host element walk for the MI355X rasterizer path.
 //
 // Every arithmetic step that decides WHERE a primitive lands (transform stack, float
-// narrowing at the rasterize_* call boundaries, Xiaolin-Wu endpoint/gradient math) follows
-// the reference expression by expression, because the ordered stream must be identical to
-// the sequence of rasterize_triangle / rasterize_point calls SoftwareRendererImp::draw_svg
-// makes (Assignments/DrawSVG/src/software_renderer.cpp:17-52, 94-265, 303-454).
+// narrowing at the rasterize_* call boundaries) follows the reference expression by
+// expression, because the ordered stream must be identical to the sequence of
+// rasterize_triangle / rasterize_line / rasterize_point / rasterize_image calls
+// SoftwareRendererImp::draw_svg makes (Assignments/DrawSVG/src/software_renderer.cpp:17-52, 94-265).
 #include "svg_stream.h"
 
 #include <cmath>
@@ -15,15 +15,6 @@
 #include "triangulation.h"  // the reference's ear-clipper, reused as-is
 
 namespace CMU462 {
-
-namespace {
-
-// Wu helpers, float in / float out (software_renderer.cpp:355-363).
-inline float wu_floor(float v) { return std::floor(v); }
-inline float wu_frac(float v) { return v - std::floor(v); }
-inline float wu_rfrac(float v) { return 1 - wu_frac(v); }
-
-}  // namespace
 
 const std::vector<srt_prim>& SvgStreamBuilder::build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate) {
   stream_.clear();
@@ -170,8 +161,6 @@ void SvgStreamBuilder::emit_point(double x, double y, const Color& c) {
   stream_.push_back(p);
 }
 
-// Xiaolin Wu anti-aliased line -> ordered rasterize_point calls (cpp:365-454). All math in
-// float, as in the reference; the stroke alpha is REPLACED by the Wu coverage, not scaled.
 void SvgStreamBuilder::emit_image(float x0, float y0, float x1, float y1, const Texture& tex) {
   srt_prim p;
   std::memset(&p, 0, sizeof p);
@@ -184,48 +173,16 @@ void SvgStreamBuilder::emit_image(float x0, float y0, float x1, float y1, const 
   stream_.push_back(p);
 }
 
+// rasterize_line(x0, y0, x1, y1, color) (cpp:303-318): ONE record; the device expands rasterize_line_xiaolinwu into its
+// rasterize_point calls (csrc/raster.hip: raster_setup + the tile kernel).  The double coordinates narrow to the call's float
+// parameters here, as at the reference's call sites; the stroke alpha travels along but is replaced by the Wu coverage.
 void SvgStreamBuilder::emit_line(float x0, float y0, float x1, float y1, Color color) {
-  const bool steep = std::abs(x1 - x0) < std::abs(y1 - y0);
-  if (steep) { std::swap(x0, y0); std::swap(x1, y1); }
-  if (x0 > x1) { std::swap(x0, x1); std::swap(y0, y1); }
-
-  const float dx = x1 - x0;
-  const float dy = y1 - y0;
-  const float gradient = (dx == 0.0f) ? 1.0f : dy / dx;
-
-  // (major, minor) -> (x, y) or (y, x)
-  auto plot = [&](float major, float minor, float alpha) {
-    color.a = alpha;
-    if (steep) emit_point(minor, major, color);
-    else       emit_point(major, minor, color);
-  };
-
-  // first endpoint
-  float xend = std::round(x0);
-  float yend = y0 + gradient * (xend - x0);
-  float xgap = wu_rfrac(x0 + 0.5f);
-  const float xpxl1 = xend;
-  const float ypxl1 = wu_floor(yend);
-  plot(xpxl1, ypxl1, wu_rfrac(yend) * xgap);
-  plot(xpxl1, ypxl1 + 1, wu_frac(yend) * xgap);
-  float intery = yend + gradient;
-
-  // second endpoint
-  xend = std::round(x1);
-  yend = y1 + gradient * (xend - x1);
-  xgap = wu_frac(x1 + 0.5f);
-  const float xpxl2 = xend;
-  const float ypxl2 = wu_floor(yend);
-  plot(xpxl2, ypxl2, wu_rfrac(yend) * xgap);
-  plot(xpxl2, ypxl2 + 1, wu_frac(yend) * xgap);
-
-  // interior; note the reference's upper bound subtracts sample_rate (cpp:434,445)
-  const float last = xpxl2 - 1 * sample_rate_;
-  for (float x = xpxl1 + 1; x <= last; ++x) {
-    plot(x, wu_floor(intery), wu_rfrac(intery));
-    plot(x, wu_floor(intery) + 1, wu_frac(intery));
-    intery += gradient;
-  }
+  srt_prim p;
+  std::memset(&p, 0, sizeof p);
+  p.kind = SRT_PRIM_LINE;
+  p.v.tri[0] = x0; p.v.tri[1] = y0; p.v.tri[2] = x1; p.v.tri[3] = y1;
+  p.rgba[0] = color.r; p.rgba[1] = color.g; p.rgba[2] = color.b; p.rgba[3] = color.a;
+  stream_.push_back(p);
 }
 
 }  // namespace CMU462

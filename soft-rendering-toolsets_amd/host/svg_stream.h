@@ -20,8 +20,8 @@ class SvgStreamBuilder : public SVGRenderer {
   // SVGRenderer interface: same as build().
   void draw_svg(SVG& svg) { build(svg, transformation, sample_rate_); }
 
-  // Walk `svg` with top-level transform svg_2_screen.  sample_rate only enters through the reference's
-  // Xiaolin-Wu loop bound (software_renderer.cpp:434,445).
+  // Walk `svg` with top-level transform svg_2_screen.  (sample_rate no longer enters: lines are single records, their
+  // Xiaolin-Wu expansion - whose loop bound depends on it, software_renderer.cpp:434,445 - happens on the device.)
   const std::vector<srt_prim>& build(SVG& svg, const Matrix3x3& svg_2_screen, size_t sample_rate);
 
   const std::vector<srt_prim>& stream() const { return stream_; }

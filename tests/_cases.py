@@ -105,6 +105,83 @@ def adversarial_stream(seed, w, h):
     return out[idx].copy()
 
 
+def _line(p, xy, rgba):
+    p["kind"] = 4
+    v = np.zeros(6, np.float32)
+    v[:4] = np.asarray(xy, np.float32)
+    p["v"] = v.view(np.float64)
+    p["rgba"] = np.asarray(rgba, np.float32)
+
+
+def line_stream(seed, w, h):
+    """Ordered stream that exercises rasterize_line_xiaolinwu (software_renderer.cpp:365-454) and its interplay with the other
+    primitives: every octant, steep / shallow, |slope| exactly 1 and 0, vertical and horizontal lines, end points on pixel
+    centres / corners / halves (round() ties), lines shorter than a pixel and of zero length (both end points on one pixel:
+    the four end-point fills overlap), lines shorter than the sample rate (the main loop's bound subtracts it), lines that
+    leave the target on every side or lie entirely outside, long lines across the whole target, huge off-target end points,
+    NaN coordinates (nothing must be drawn, nothing may hang), translucent and out-of-gamut colours (the stroke
+    alpha is replaced by the coverage), under and over translucent triangles and points (painter's order)."""
+    rng = np.random.default_rng(seed)
+    prims = []
+
+    def color():
+        c = rng.random(3)
+        if rng.random() < 0.15:
+            c = c * 2.5 - 0.7
+        return [c[0], c[1], c[2], [0.0, 0.3, 1.0, 0.6][rng.integers(0, 4)]]
+
+    def add(kind, xy):
+        p = np.zeros((), PRIM_DTYPE)
+        (_line if kind == 4 else _tri if kind == 1 else _pt)(p, xy, color())
+        prims.append(p)
+
+    # a layer of translucent triangles underneath
+    for _ in range(12):
+        add(1, rng.random(6) * np.tile([w, h], 3))
+    # random segments of every length and direction, end points on a 1/4 grid (round() ties, exact halves) and arbitrary
+    for k in range(70):
+        a = rng.random(2) * [w + 16, h + 16] - 8
+        ln = rng.choice([0.3, 1.0, 2.5, 6.0, 20.0, 90.0])
+        ang = rng.random() * 2 * np.pi
+        b = a + ln * np.array([np.cos(ang), np.sin(ang)])
+        if k % 3 == 0:
+            a, b = np.round(a * 4) / 4, np.round(b * 4) / 4
+        add(4, [a[0], a[1], b[0], b[1]])
+    # exact slopes: horizontal, vertical, +-1 (dx == dy: `steep` is false, the tie goes to the shallow branch)
+    for d in ((25, 0), (0, 25), (25, 25), (25, -25), (-25, 25), (-25, -25), (-25, 0), (0, -25), (1, 1), (3, 3), (0.5, 0.5)):
+        a = np.floor(rng.random(2) * [w - 30, h - 30]) + 15 + rng.choice([0.0, 0.5, 0.25])
+        add(4, [a[0], a[1], a[0] + d[0], a[1] + d[1]])
+    # zero length and sub-pixel: the four end-point fills land on one or two pixels
+    for xy in ((10, 10, 10, 10), (20.5, 7.5, 20.5, 7.5), (30.25, 9.75, 30.3, 9.8), (5.5, 30.5, 5.9, 30.6), (40.49, 12.0, 40.51, 12.0),
+               (12.0, 40.49, 12.0, 40.51)):
+        add(4, xy)
+    # lengths around the sample rate (the main loop runs from xpxl1 + 1 to xpxl2 - sample_rate)
+    for L in (1, 2, 3, 4, 5, 6, 7):
+        y = 3 + 2 * L
+        add(4, [50.0, y, 50.0 + L, y + 0.3 * L])
+        add(4, [y + 0.5, 45.0, y + 0.8, 45.0 + L])
+    # across the target, through its corners and borders, and entirely outside
+    add(4, [-30, -20, w + 25, h + 35]); add(4, [w + 10, -10, -10, h + 10]); add(4, [-5, h / 2, w + 5, h / 2 + 0.7])
+    add(4, [w / 2 + 0.2, -9, w / 2 - 0.4, h + 9]); add(4, [0, 0, w, h]); add(4, [0, h - 1, w - 1, 0])
+    add(4, [-50, -50, -10, -3]); add(4, [w + 5, 5, w + 60, 40]); add(4, [5, h + 3, 60, h + 3]); add(4, [-0.4, 3, -0.4, 30]); add(4, [3, -0.6, 40, -0.6])
+    add(4, [w - 0.5, 2, w - 0.5, h - 2]); add(4, [2, h - 0.5, w - 2, h - 0.5]); add(4, [w - 1, 0, w - 1, h]); add(4, [0, h - 1, w, h - 1])
+    # far end points (long main loops, mostly off target) and non-finite coordinates
+    add(4, [-3000.5, 10, w + 10, 40]); add(4, [20, -4000, 60, h + 5]); add(4, [-1e5, -1e5, w / 2, h / 2]); add(4, [w / 2, h / 2, 2e5, 1.5e5])
+    # (infinite coordinates are not here: the reference's main loop never ends on them - `++x` on an infinite float - and the
+    #  product refuses such lines, tests/test_raster_gpu.py::test_unwalkable_lines_are_refused)
+    add(4, [np.nan, 5, 20, 30]); add(4, [5, np.nan, 20, 30]); add(4, [5, 6, np.nan, 30]); add(4, [5, 6, 20, np.nan])
+    add(4, [np.nan, np.nan, np.nan, np.nan])
+    # points and triangles in between and on top
+    for _ in range(15):
+        add(2, np.floor(rng.random(2) * [w, h]))
+    for _ in range(10):
+        add(1, rng.random(6) * np.tile([w, h], 3))
+    out = np.stack(prims).astype(PRIM_DTYPE)
+    idx = np.arange(len(out))
+    rng.shuffle(idx)
+    return out[idx].copy()
+
+
 def random_triangles(seed, n, w, h, max_extent, alpha=(0.2, 1.0)):
     """n random triangles (for size-independent property tests and the benchmark's synthetic mode)."""
     rng = np.random.default_rng(seed)

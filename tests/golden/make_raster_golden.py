@@ -7,7 +7,8 @@ Run in the authoring container only (needs /root/reference and `make -C oracle r
 
 For every case the reference's SoftwareRendererImp (compiled from its sources by oracle/Makefile into
 oracle/_ref/libref_raster.so) renders the image; the fixture stores
-  prims      the ordered primitive stream (inputs; from the SVG via our host walk, or synthetic)
+  prims      the ordered primitive stream (inputs; from the SVG via our host walk - one record per rasterize_triangle /
+             rasterize_line / rasterize_point / rasterize_image call - or synthetic)
   rgba       the reference's RGBA8 render target            (expected output)
   ss_sha256  SHA-256 of the reference's float supersample buffer (expected output, hashed: it is 16 B/sample)
   meta       w, h, sample_rate
@@ -23,7 +24,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import _harness as H  # noqa: E402
-from _cases import adversarial_stream, image_stream  # noqa: E402
+from _cases import adversarial_stream, image_stream, line_stream  # noqa: E402
 
 SVG_DIR = os.path.join(H.REF_ROOT, "Assignments/DrawSVG/svg")
 
@@ -100,6 +101,18 @@ def main():
             source=np.array("tests/_cases.py:adversarial_stream"),
         )
         print(f"adversarial ss{sr}: {len(prims)} prims rgba sha {H.sha(rgba)[:12]}")
+
+    # rasterize_line_xiaolinwu on LINE records (the device expands them): every octant, ties, sub-pixel, off-target, non-finite
+    for sr in (() if (only_images or only) else (1, 2, 3, 4, 7)):
+        w, h = 83, 67
+        prims = line_stream(seed=4321 + sr, w=w, h=h)
+        rgba, ss = H.ref_raster_prims(prims, w, h, sr, want_samples=True)
+        np.savez_compressed(
+            os.path.join(HERE, f"raster_lines_ss{sr}.npz"),
+            prims=prims, rgba=rgba, ss_sha256=np.array(H.sha(ss)), meta=np.array([w, h, sr], np.int64),
+            source=np.array("tests/_cases.py:line_stream"),
+        )
+        print(f"lines ss{sr}: {len(prims)} prims ({int((prims['kind'] == 4).sum())} lines) rgba sha {H.sha(rgba)[:12]}")
 
     # synthetic image streams: textures with the reference's mip chains, images folded over column / row 0,
     # minified below the last level, magnified, drawn under and over translucent triangles

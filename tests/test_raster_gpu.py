@@ -198,3 +198,87 @@ def test_images_match_oracle(srt, sr):
     want, _, _ = H.oracle_raster_frame(sub, w, h, sr, textures=only)
     assert np.array_equal(again, want)
     ren.close()
+
+
+@pytest.mark.parametrize("sr", [1, 2, 3, 4, 5, 8, 16, 32])
+@pytest.mark.parametrize("wh", [(83, 67), (9, 140), (150, 11), (256, 256)])
+def test_lines_match_oracle(srt, sr, wh):
+    """SRT_PRIM_LINE records: rasterize_line_xiaolinwu expanded on the device (raster_setup: end points, gradient, the serial
+    intery chain; tile kernel: the fills) against the oracle's restatement of the reference loop - RGBA8, the float sample
+    buffer and the number of in-bounds fill_sample calls."""
+    from _cases import line_stream
+
+    w, h = wh
+    prims = line_stream(5000 + 31 * sr + w, w, h)
+    rgba, ss, st = render(srt, prims, w, h, sr, samples=True)
+    o_rgba, o_ss, c = H.oracle_raster_frame(prims, w, h, sr, want_samples=True)
+    assert np.array_equal(rgba, o_rgba), f"{(rgba != o_rgba).any(axis=2).sum()} pixels differ"
+    assert np.array_equal(ss.view(np.uint32), o_ss.view(np.uint32))
+    assert (st.sample_tests, st.fragments, st.point_samples) == (int(c[0]), int(c[2]), int(c[3]))
+
+
+def test_long_lines_and_growing_storage(srt):
+    """Thousands of long lines on a 1024 x 768 target: the first frame's guesses for the line tables and the packed bin lists
+    are too small, the library grows them and repeats the frame; a resubmission of the same stream, a different stream and the
+    first one again all give the oracle's image (checked on a crop-sized twin, the scalar oracle is slow at full size)."""
+    rng = np.random.default_rng(12)
+    w, h, sr = 1024, 768, 2
+
+    def lines(n, seed):
+        r = np.random.default_rng(seed)
+        p = np.zeros(n, H.PRIM_DTYPE)
+        p["kind"] = 4
+        v = np.zeros((n, 6), np.float32)
+        v[:, 0:4] = r.random((n, 4)) * [w, h, w, h]
+        p["v"] = v.view(np.float64).reshape(n, 3)
+        p["rgba"][:, :3] = r.random((n, 3))
+        return p
+
+    a, b = lines(6000, 1), lines(9000, 2)
+    ren = srt.SoftwareRenderer(0)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(sr)
+    img_a = ren.draw_stream(a).copy()
+    assert np.array_equal(ren.draw_stream(a), img_a)          # identical resubmission: nothing uploaded, nothing binned
+    img_b = ren.draw_stream(b).copy()
+    assert not np.array_equal(img_a, img_b)
+    assert np.array_equal(ren.draw_stream(a), img_a)
+    ren.close()
+    # the same streams against the oracle at a size it finishes quickly (coordinates scaled: other lines, same code paths)
+    for s, n in ((1, 700), (2, 900)):
+        p = lines(n, s)
+        v = p["v"].view(np.float32).reshape(n, 6) * np.float32(0.25)
+        p["v"] = v.view(np.float64).reshape(n, 3)
+        got, _, _ = render(srt, p, w // 4, h // 4, sr)
+        want, _, _ = H.oracle_raster_frame(p, w // 4, h // 4, sr)
+        assert np.array_equal(got, want)
+    del rng
+
+
+def test_unwalkable_lines_are_refused(srt):
+    """The reference's main loop `for (float x = xpxl1 + 1; x <= xpxl2 - sample_rate; ++x)` never ends when x reaches 2^24 or is
+    infinite; such a line is refused by the product (SRT_ERR_UNSUPPORTED at resolve) and by the oracle alike.  A line with NaN
+    coordinates draws nothing, one that merely ends far outside the target is drawn."""
+    w, h, sr = 64, 48, 2
+
+    def one(xy):
+        p = np.zeros(1, H.PRIM_DTYPE)
+        p["kind"] = 4
+        v = np.zeros(6, np.float32); v[:4] = xy
+        p["v"] = v.view(np.float64)
+        p["rgba"] = [0.1, 0.2, 0.3, 1.0]
+        return p
+
+    for xy in ((5, 6, np.inf, 30), (-np.inf, 6, 20, 30), (5, np.inf, 20, 30), (5, 6, 3.0e7, 30), (-2.0e7, 1, 2.0e7, 40)):
+        ren = srt.SoftwareRenderer(0)
+        ren.set_render_target(None, w, h)
+        ren.set_sample_rate(sr)
+        with pytest.raises(srt.SrtError) as e:
+            ren.draw_stream(one(xy))
+        assert e.value.status == -4, xy
+        ren.close()
+        assert H.oracle().srt_oracle_raster_frame(H.P(one(xy)), 1, w, h, sr, H.P(np.zeros((h, w, 4), np.uint8)), None, None) == -1
+    for xy in ((np.nan, 6, 20, 30), (5, 6, 20, np.nan), (-9.0e6, -20, 70, 60)):
+        got, _, _ = render(srt, one(xy), w, h, sr)
+        want, _, _ = H.oracle_raster_frame(one(xy), w, h, sr)
+        assert np.array_equal(got, want)

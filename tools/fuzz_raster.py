@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the rasterizer: seeded random frames (random size, sample rate 1..6 / 8 / 16, random and
-adversarial triangles, points, image records over random rectangles with random textures) through the C ABI against the
+adversarial triangles, points, lines, image records over random rectangles with random textures) through the C ABI against the
 CPU oracle: RGBA8 and the float supersample buffer bit for bit, and the work counters.  usage: fuzz_raster.py [first] [count]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,21 @@ for seed in range(first, first + count):
         v[:, 3] = y0 + rng.choice([0.0, 0.5, 3.0, 17.25, 90.0], n) * rng.random(n)
         img["v"] = v.view(np.float64).reshape(-1, 3)
         parts.append(img)
+    if rng.random() < 0.7:     # SRT_PRIM_LINE records: rasterize_line_xiaolinwu expanded on the device
+        n = int(rng.integers(1, 60))
+        ln = np.zeros(n, PRIM_DTYPE)
+        ln["kind"] = 4
+        v = np.zeros((n, 6), np.float32)
+        a = rng.uniform(-12, [w + 12, h + 12], (n, 2))
+        length = rng.choice([0.0, 0.4, 1.0, 3.0, 9.0, 40.0, 300.0], n) * rng.random(n)
+        ang = rng.random(n) * 2 * np.pi
+        b = a + length[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1)
+        snap = rng.random(n) < 0.4                      # end points on quarter pixels: round() ties, exact slopes
+        a[snap] = np.round(a[snap] * 4) / 4; b[snap] = np.round(b[snap] * 4) / 4
+        v[:, 0:2] = a; v[:, 2:4] = b
+        ln["v"] = v.view(np.float64).reshape(-1, 3)
+        ln["rgba"] = rng.random((n, 4)).astype(np.float32)
+        parts.append(ln)
     prims = np.concatenate(parts)
     prims = prims[rng.permutation(len(prims))] if len(prims) else prims
     ren = srt_amd.SoftwareRenderer(0)

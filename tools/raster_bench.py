@@ -21,12 +21,31 @@ out = ren.resolve()
 print("matches golden:", bool(np.array_equal(out, g["rgba"])))
 st = ren.stats()
 stream = torch.cuda.current_stream().cuda_stream
+redraw = os.environ.get("SRT_BENCH_REDRAW") == "1"      # frames of an unchanged stream: the tile kernel alone
 for _ in range(3):
-    ren.resolve_device(stream)
+    ren.invalidate(); ren.resolve_device(stream)
 torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(frames):
+    if not redraw:
+        ren.invalidate()                                  # a FULL frame: setup + binning + tiles
     ren.resolve_device(stream)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / frames
-print(f"{name}: {dt*1e3:.3f} ms/frame, {st.fragments/dt/1e6:.0f} Mfrags/s, {st.sample_tests/dt/1e9:.1f} G tests/s, bin entries {st.bin_entries}, list bytes {st.list_bytes}")
+print(f"{name}{' (redraw)' if redraw else ''}: {dt*1e3:.3f} ms/frame, {st.fragments/dt/1e6:.0f} Mfrags/s, {st.sample_tests/dt/1e9:.1f} G tests/s, bin entries {st.bin_entries}, list bytes {st.list_bytes}")
+# end to end through the host-buffer boundary: submit (identical stream: no upload) / new stream (upload) + frame + read-back
+fb = np.empty((h, w, 4), np.uint8)
+ren.set_render_target(fb, w, h)
+ren.set_sample_rate(sr)
+prims = g["prims"]
+ren.draw_stream(prims)
+t = time.perf_counter()
+for _ in range(frames):
+    ren.draw_stream(prims)
+same = (time.perf_counter() - t) / frames
+alt = prims.copy(); alt["rgba"][:, 0] *= 0.5
+t = time.perf_counter()
+for k in range(frames):
+    ren.draw_stream(alt if k % 2 else prims)
+new = (time.perf_counter() - t) / frames
+print(f"  draw_stream wall (clear + submit + resolve into a pinned host buffer): same stream {same*1e3:.3f} ms, alternating streams {new*1e3:.3f} ms")
