@@ -119,38 +119,91 @@ def pt_cpu_baseline(scene, w, h, depth, seed, pt, budget_s=15.0):
     return out
 
 
+def _raster_roofline(prof, tag, kernel_prefix, ms_tiles_live, alg_bytes):
+    """The tile kernel against vector-instruction issue (what binds it; counters from the committed PMC passes of the same
+    kernel sources) with SURVEY.md 8(d)'s HBM figure beside it."""
+    hbm = {"bound": "hbm", "achieved": alg_bytes / (ms_tiles_live * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / (ms_tiles_live * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "SURVEY.md 8(d): 40 B x (primitive, tile) entries + 4 B x pixels over the tile kernel's live duration; the 256 MiB "
+                   "supersample buffer never leaves the CUs, so this is tiny by design"}
+    if not prof or tag not in prof:
+        return dict(hbm, traffic=None)
+    t = prof[tag]["tiles_per_frame"]
+    kname, kus = next(((k, v["avg_us"]) for k, v in prof[tag]["kernels"].items() if k.startswith(kernel_prefix)), (None, None))
+    rate = t["SQ_INSTS_VALU"] / (kus * 1e-6)
+    tr = prof[tag].get("traffic_per_frame")
+    return {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_GUIDE / 1e9, "unit": "G wave-instructions/s",
+            "frac": rate / VALU_PEAK_GUIDE, "frac_ubench_ceiling": rate / (SIMDS / (VALU_NS_UBENCH * 1e-9)),
+            "traffic": tr["hbm_bytes"] if tr else None, "traffic_detail": tr,
+            "kernel": kname, "kernel_us_profiled": kus, "kernel_us_live": ms_tiles_live * 1e3,
+            "valu_lane_utilisation": (t.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * t["SQ_ACTIVE_INST_VALU"])) if t.get("SQ_ACTIVE_INST_VALU") else None,
+            "wave_cycles_waiting": t.get("SQ_WAIT_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
+            "wave_cycles_issuing": t.get("SQ_ACTIVE_INST_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
+            "lds_instructions_per_frame": t.get("SQ_INSTS_LDS"), "lds_bank_conflict_cycles_per_frame": t.get("SQ_LDS_BANK_CONFLICT"),
+            "lds_active_cycles_per_frame": t.get("SQ_LDS_IDX_ACTIVE"),
+            "kernels_us_profiled": {k: v["avg_us"] for k, v in prof[tag]["kernels"].items()},
+            "source": prof["_file"], "hbm": hbm}
+
+
+def _timed_frames(torch, ren, stream, frames, full):
+    """ms per frame (HIP events on the launch stream) of `frames` device frames; full: setup + binning + tiles (the stream is
+    resident, what the library derived from it is discarded before every frame), else the tile kernel alone (a redraw)."""
+    for _ in range(3):
+        if full:
+            ren.invalidate()
+        ren.resolve_device(stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(frames):
+        if full:
+            ren.invalidate()
+        ren.resolve_device(stream)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / frames
+
+
 def raster_bench(device, frames=30, warmup=3):
-    """BASELINE configs[1]: basic/test3.svg (1963 triangles + Wu-line points), 1024x1024, supersample 4.
-    A frame = clear + ordered fill + resolve with the primitive stream resident in HBM."""
+    """BASELINE configs[1]: basic/test3.svg (1963 triangles + 1992 lines), 1024x1024, supersample 4.
+    `value` follows SURVEY.md 8(d): covered fragments per second of the `draw_svg` WALL - DrawSVG's redraw through the drop-in
+    class (stream build on the host, upload, setup, binning, tiles, resolve, read-back into the application's framebuffer),
+    measured in oracle/_ref/libdropin_raster.so = SoftwareRendererHIP inside the reference's own DrawSVG sources; without that
+    library (it is built in the authoring container) the same steps through the C ABI from the prebuilt stream.  The device-only
+    figures - a full frame of the resident stream, and the tile kernel alone - are reported beside it."""
+    import ctypes
+    import glob
+
     import torch
 
     import _harness as H
     import srt_amd
 
+    del warmup
     g = np.load(os.path.join(H.GOLDEN, "raster_cfg2_test3_1024_ss4.npz"))
     w, h, sr = (int(x) for x in g["meta"])
     ren = srt_amd.SoftwareRenderer(device)
-    ren.set_render_target(None, w, h)
+    fb = np.empty((h, w, 4), np.uint8)
+    ren.set_render_target(fb, w, h)
     ren.set_sample_rate(sr)
-    ren.clear_target()
-    ren.submit(g["prims"])
-    out = ren.resolve()                      # uploads the stream, checks the result
+    out = ren.draw_stream(g["prims"]).copy()     # uploads the stream, checks the result
     ok = bool(np.array_equal(out, g["rgba"]))
     st = ren.stats()
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(warmup):
-        ren.resolve_device(stream)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms_full = _timed_frames(torch, ren, stream, frames, True)
+    ms_tiles = _timed_frames(torch, ren, stream, frames, False)
+    # the boundary from the prebuilt stream: clear + submit + resolve into the pinned framebuffer (no SVG walk)
+    alt = g["prims"].copy()
+    alt["rgba"][:, 0] *= 0.5
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(frames):
-        ren.resolve_device(stream)
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms = e0.elapsed_time(e1) / frames
-    alg_bytes = 40.0 * st.bin_entries + 4.0 * w * h          # SURVEY.md §8(d) rasterizer formula (fused resolve)
+    for k in range(frames):
+        ren.draw_stream(alt if k % 2 else g["prims"])
+    abi_new_ms = (time.perf_counter() - t0) * 1e3 / frames
+    t0 = time.perf_counter()
+    for k in range(frames):
+        ren.draw_stream(g["prims"])
+    abi_same_ms = (time.perf_counter() - t0) * 1e3 / frames
+    alg_bytes = 40.0 * st.bin_entries + 4.0 * w * h          # SURVEY.md 8(d) rasterizer formula (fused resolve)
     o_rgba, _, counts = H.oracle_raster_frame(g["prims"], w, h, sr)       # fragment count of the frame (checker)
     use_ref = os.path.exists(os.path.join(H.ORACLE_DIR, "_ref", "libref_raster.so"))
     t = time.perf_counter()
@@ -161,39 +214,36 @@ def raster_bench(device, frames=30, warmup=3):
     cpu_s = time.perf_counter() - t
     ok = ok and bool(np.array_equal(r_rgba, out))
     ren.close()
+    # DrawSVG's redraw through the drop-in class
+    dropin, wall = os.path.join(H.ORACLE_DIR, "_ref", "libdropin_raster.so"), None
+    svg = os.path.join(H.GOLDEN, "svg", "test3.svg")
+    if os.path.exists(dropin) and os.path.exists(svg):
+        lib = ctypes.CDLL(dropin)
+        ms3 = (ctypes.c_double * 3)()
+        d_out = np.zeros((h, w, 4), np.uint8)
+        if lib.dropin_raster_bench(svg.encode(), device, w, h, sr, frames, ms3, H.P(d_out)) == 0:
+            wall = {"draw_svg_wall_ms": ms3[0], "draw_svg_redraw_wall_ms": ms3[1], "host_stream_build_ms": ms3[2],
+                    "framebuffer_equals_reference_golden": bool(np.array_equal(d_out, g["rgba"])),
+                    "what": "oracle/_ref/libdropin_raster.so: CMU462::SoftwareRendererHIP linked into the reference's DrawSVG sources and driven "
+                            "like DrawSVG::redraw (clear_target, set_svg_2_screen, draw_svg); draw_svg_wall_ms = the view moves every frame "
+                            "(SVG walk + triangulation on the host, upload, setup, binning, tiles, resolve, 4 MiB read-back into the "
+                            "application's framebuffer), draw_svg_redraw_wall_ms = unchanged view (tile kernel + read-back)"}
+            ok = ok and wall["framebuffer_equals_reference_golden"]
+    e2e_ms = wall["draw_svg_wall_ms"] if wall else abi_new_ms
     # what binds the tile kernel: vector-instruction issue and LDS, from the committed SQ counter passes of the same kernel sources
-    import glob
     prof, why_not = None, "no committed PMC pass for the rasterizer"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_raster.json")), reverse=True):
         try:
             doc = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if doc.get("kernel_source_sha16") == kernel_source_sha():
+        if doc.get("kernel_source_sha16") == kernel_source_sha() and "cfg2" in doc:
             prof, why_not = doc, None
             prof["_file"] = os.path.relpath(path, ROOT)
             break
         why_not = f"{os.path.relpath(path, ROOT)} was taken on other kernel sources: counters not reported"
-    hbm = {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "note": "SURVEY.md 8(d): 40 B x (primitive, tile) entries + 4 B x pixels; the 256 MiB supersample buffer never leaves the CUs, "
-                   "so this is tiny by design"}
-    roof = dict(hbm, traffic=None)
-    if prof:
-        t = prof["raster_tiles_per_frame"]
-        tiles_us = next((v["avg_us"] for k, v in prof["kernels"].items() if "raster_tiles<false" in k), None)
-        rate = t["SQ_INSTS_VALU"] / (tiles_us * 1e-6)
-        roof = {"bound": "valu", "achieved": rate / 1e9, "peak": VALU_PEAK_GUIDE / 1e9, "unit": "G wave-instructions/s",
-                "frac": rate / VALU_PEAK_GUIDE, "frac_ubench_ceiling": rate / (SIMDS / (VALU_NS_UBENCH * 1e-9)), "traffic": None,
-                "kernel": "raster_tiles<false, 16>", "kernel_us_profiled": tiles_us,
-                "valu_lane_utilisation": (t.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * t["SQ_ACTIVE_INST_VALU"])) if t.get("SQ_ACTIVE_INST_VALU") else None,
-                "wave_cycles_waiting": t.get("SQ_WAIT_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
-                "wave_cycles_issuing": t.get("SQ_ACTIVE_INST_ANY", 0.0) / t["SQ_WAVE_CYCLES"] if t.get("SQ_WAVE_CYCLES") else None,
-                "lds_instructions_per_frame": t.get("SQ_INSTS_LDS"), "lds_bank_conflict_cycles_per_frame": t.get("SQ_LDS_BANK_CONFLICT"),
-                "lds_active_cycles_per_frame": t.get("SQ_LDS_IDX_ACTIVE"),
-                "kernels_us_profiled": {k: v["avg_us"] for k, v in prof["kernels"].items()},
-                "source": prof["_file"], "hbm": hbm}
-    elif why_not:
+    roof = _raster_roofline(prof, "cfg2", "raster_tiles<false", ms_tiles, alg_bytes)
+    if not prof and why_not:
         roof["counters"] = why_not
     stress = None
     sp = os.path.join(H.GOLDEN, "stress_degenerate2_1024_ss4.npz")
@@ -201,40 +251,48 @@ def raster_bench(device, frames=30, warmup=3):
         gs = np.load(sp)
         sw, sh, ssr = (int(x) for x in gs["meta"])
         r2 = srt_amd.SoftwareRenderer(device)
-        r2.set_render_target(None, sw, sh)
+        fb2 = np.empty((sh, sw, 4), np.uint8)
+        r2.set_render_target(fb2, sw, sh)
         r2.set_sample_rate(ssr)
-        r2.clear_target()
-        r2.submit(gs["prims"])
-        o2 = r2.resolve()
+        o2 = r2.draw_stream(gs["prims"]).copy()
         st2 = r2.stats()
-        r2.resolve_device(stream)
-        torch.cuda.synchronize()
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
+        sms = _timed_frames(torch, r2, stream, 5, True)
+        sms_tiles = _timed_frames(torch, r2, stream, 5, False)
+        t0 = time.perf_counter()
         for _ in range(5):
-            r2.resolve_device(stream)
-        a1.record()
-        torch.cuda.synchronize()
-        sms = a0.elapsed_time(a1) / 5
-        stress = {"workload": "DrawSVG hardcore/02_degenerate_square2.svg 1024x1024 supersample=4", "ms_per_frame": sms,
+            r2.invalidate(); r2.draw_stream(gs["prims"])
+        s_wall = (time.perf_counter() - t0) * 1e3 / 5
+        stress = {"workload": "DrawSVG hardcore/02_degenerate_square2.svg 1024x1024 supersample=4", "ms_per_frame": sms, "tiles_ms": sms_tiles,
+                  "wall_ms_per_frame_through_the_c_abi": s_wall,
                   "sample_tests": int(st2.sample_tests), "fragments": int(st2.fragments), "sample_tests_per_s": st2.sample_tests / (sms * 1e-3),
-                  "mfrags_per_s": st2.fragments / (sms * 1e-3) / 1e6, "bit_exact_vs_reference_golden": bool(np.array_equal(o2, gs["rgba"])),
+                  "mfrags_per_s": st2.fragments / (s_wall * 1e-3) / 1e6, "bit_exact_vs_reference_golden": bool(np.array_equal(o2, gs["rgba"])),
+                  "roofline": _raster_roofline(prof, "stress", "raster_tiles<false", sms_tiles, 40.0 * st2.bin_entries + 4.0 * sw * sh),
                   "reference_cpu_s": 22.7, "reference_cpu_source": "BASELINE.md section 2 (survey-time probe, 1 thread)"}
         r2.close()
     return {
-        "metric": "Mfrags/s triangle fill", "value": st.fragments / (ms * 1e-3) / 1e6, "unit": "Mfrags/s",
-        "ms_per_frame": ms, "wall_ms_per_frame": wall * 1e3 / frames, "frames": frames,
+        "metric": "Mfrags/s triangle fill", "value": st.fragments / (e2e_ms * 1e-3) / 1e6, "unit": "Mfrags/s",
+        "value_is": "covered fragments / draw_svg wall (SURVEY.md 8(d)): " + ("DrawSVG's redraw through the drop-in class, the view moving every frame"
+                                                                          if wall else "clear + submit + resolve through the C ABI, a new stream every frame"),
+        "wall_ms_per_frame": e2e_ms, "draw_svg": wall,
+        "c_abi_wall_ms": {"new_stream_every_frame": abi_new_ms, "same_stream": abi_same_ms,
+                          "what": "srt_raster_clear + srt_raster_submit + srt_raster_resolve into the pinned framebuffer from Python (ctypes), "
+                                  "no SVG walk"},
+        "device_ms_per_frame": ms_full, "device_tiles_only_ms": ms_tiles,
+        "device_mfrags_per_s": st.fragments / (ms_full * 1e-3) / 1e6,
+        "binning_share_of_device_frame": max(0.0, 1.0 - ms_tiles / ms_full), "frames": frames,
         "config": {"workload": "DrawSVG basic/test3.svg 1024x1024 supersample=4 (BASELINE configs[1])",
-                   "triangles": int((g["prims"]["kind"] == 1).sum()), "points": int((g["prims"]["kind"] == 2).sum()),
+                   "triangles": int((g["prims"]["kind"] == 1).sum()), "lines": int((g["prims"]["kind"] == 4).sum()),
+                   "points": int((g["prims"]["kind"] == 2).sum()),
                    "fragments": int(st.fragments), "sample_tests": int(st.sample_tests), "bin_entries": int(st.bin_entries)},
-        "sample_tests_per_s": st.sample_tests / (ms * 1e-3),
+        "sample_tests_per_s": st.sample_tests / (e2e_ms * 1e-3),
         "bit_exact_vs_reference_golden": ok, "dtype": "f64 edge functions / f32 blend",
         "roofline": roof, "list_bytes": int(st.list_bytes), "stress": stress,
         "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1,
                          "kind": "reference" if use_ref else "port",
                          "sample": (("oracle/_ref/libref_raster.so = the reference's SoftwareRendererImp (g++ -O2)" if use_ref
                                      else "oracle/raster_oracle.c")
-                                    + f", one full frame of the same stream in {cpu_s * 1e3:.0f} ms, output equals the HIP frame")},
+                                    + f", one full frame of the same stream (clear + rasterize_* + resolve, no SVG walk) in {cpu_s * 1e3:.0f} ms, "
+                                      "output equals the HIP frame")},
     }
 
 
@@ -308,6 +366,21 @@ def pt_roofline(cnt, rays_per_launch, kernel_ms, doc, why_not, kernel, scratch_b
     return out
 
 
+def ray_state_bytes(rays_per_launch, cams_per_launch, stream_counters=None):
+    """SURVEY.md 8(d)'s last term - ray state that goes through memory per launch - and how it is made up.  Every kernel form: a 32-byte
+    record per shaded bounce, written once and read once (a bounce = three rays issued by the reference), and one 16-byte store per
+    sample, read again by the ordered reduction.  The streamed forms add what passes between their kernels, from DEVICE counters of the
+    launch (srt_pt_stream_counters): the saved path state per alive slot and generation and the ray / list / hit traffic per queued
+    entry, at the byte counts the kernels' layout has."""
+    bounces = max(0.0, (rays_per_launch - cams_per_launch) / 3.0)
+    terms = {"bounce_records": 64.0 * bounces, "sample_stores_and_reduction": 32.0 * cams_per_launch}
+    if stream_counters:
+        terms["slot_state"] = float(stream_counters["alive_slot_generations"] * stream_counters["bytes_per_alive_slot_generation"])
+        terms["queued_entries"] = float(stream_counters["entries_queued"] * stream_counters["bytes_per_queued_entry"])
+        terms["device_counters"] = {k: stream_counters[k] for k in ("entries_queued", "alive_slot_generations")}
+    return sum(v for v in terms.values() if isinstance(v, float)), terms
+
+
 def cfg5_bench(device, args, steps=4):
     """BASELINE configs[4]'s workload on one GPU as a second object of the line: the Cornell box with a 131 072-triangle glass
     mesh (80 127-node BVH<Triangle>, depth 18) and the mirror sphere, 1024 x 1024, 64 spp per step.  The streamed sweeps
@@ -365,32 +438,41 @@ def cfg5_bench(device, args, steps=4):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     rays, cams = pt.ray_count(reset=True)
+    # the same steps on ONE stream (no overlap of consecutive epochs): what a step costs on its own, wall clock
+    no_overlap_ms = None
+    if nstreams > 1:
+        t1 = time.perf_counter()
+        for i in range(steps):
+            pt.render_epoch_device(streams[0].cuda_stream, args.seed, i * spp, spp, tiles[0].data_ptr())
+        torch.cuda.synchronize()
+        no_overlap_ms = (time.perf_counter() - t1) * 1e3 / steps
+        pt.ray_count(reset=True)
     # one more epoch on its own for the kernels' own durations (HIP events inside the library; not part of `value`)
     pt.kernel_time(enable=True)
     if form >= 3:
         pt.stream_times(enable=True)
+        pt.stream_counters(reset=True)
     pt.render_epoch_device(streams[0].cuda_stream, args.seed, steps * spp, spp, tiles[0].data_ptr())
     torch.cuda.synchronize()
-    pt.ray_count(reset=True)
+    rays_1, cams_1 = pt.ray_count(reset=True)
     ms_total, launches = pt.kernel_time(enable=False)
     kernel_ms = ms_total / max(1, launches)
-    split = None
+    split = sc = None
     if form >= 3:
         ms3, gens = pt.stream_times(enable=False)
         split = dict(ms3)
         split["generations_enqueued_per_step"] = gens
+        sc = pt.stream_counters(reset=True)
     rng = np.random.default_rng(1)
     n = 1 << 15
     xs, ys = rng.integers(0, W, n).astype(np.uint32), rng.integers(0, H, n).astype(np.uint32)
     pt.trace_samples(args.seed, xs, ys, rng.integers(0, spp * steps, n).astype(np.uint32))
     cnt = pt.counters()
     doc, why_not = profile_doc("cfg5", W, spp, 1)
-    bounces = max(0.0, (rays - cams) / steps / 3.0)
-    scratch = 64.0 * bounces + 32.0 * cams / steps
-    if form >= 3:
-        scratch += (rays / steps / 2.8) * 2 * 30 * 4 + 0.32 * rays / steps * (2 * 36 + 2 * 8)
+    scratch, scratch_terms = ray_state_bytes(rays / steps, cams / steps, sc)
     out = {
         "metric": "Mrays/s", "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": 1, "steps": steps, "ms_per_step": elapsed * 1e3 / steps,
+        "ms_per_step_no_overlap": no_overlap_ms,
         "config": {"workload": f"Scotty3D Pathtracer: Cornell box + 131 072-triangle glass mesh + mirror sphere (BASELINE configs[4] on one GPU; seeded "
                                f"procedural stand-in for the Stanford dragon, a missing blob of the reference checkout), {W}x{H}, {spp} spp per step, "
                                f"depth {args.depth}, BVH on", "triangles": 131072, "bvh_nodes": 80127, "kernel_form": form},
@@ -398,14 +480,82 @@ def cfg5_bench(device, args, steps=4):
         "camera_samples_per_s": cams / elapsed, "rays": rays, "rays_per_camera_sample": rays / max(1, cams),
         "image_sha256_16": hashlib.sha256(acc.cpu().numpy().tobytes()).hexdigest()[:16],
         "roofline": pt_roofline(cnt, rays / steps, kernel_ms, doc, why_not,
-                                "pt_wave_kernel<.., 4, ..> + pt_compact_kernel + pt_cast_kernel (every kernel of one epoch)" if form == 4 else str(form),
-                                scratch, {"stream_kernels_ms": split,
+                                "pt_wave_kernel<.., 4, .., 1> (resolve) + <.., 2> (probe) + pt_compact_kernel + pt_cast_kernel (every kernel of one epoch)" if form == 4 else str(form),
+                                scratch, {"stream_kernels_ms": split, "ray_state_terms": scratch_terms,
                                           "working_set": "2.6 MB of interior records + 6.3 MB of triangles (+ 6.3 MB normals): L2 (4 MiB per XCD) / Infinity Cache resident"}),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt, budget_s=8.0)
     pt.close()
     return out
+
+
+def group_bench(args):
+    """`--group N[,M,..]`: the in-process multi-GPU path the C++ drop-in uses (srt_pt_create_multi: a context per rank, image tiles
+    round-robin, ONE gather per epoch to rank 0) - timed as srt_pt_group_render_epoch_device, per N.  With N devices it is the
+    RCCL path of csrc/pt_group.cpp (grouped ncclGather over xGMI); on a box with fewer devices the ranks share device 0 (a
+    REHEARSAL: the ranks' kernels run concurrently on one GPU, the gather is device-to-device copies, and the line says so).
+    Per N: wall ms per step, Mrays/s, the image hash against N = 1, each rank's own kernel time and the exchange step
+    (gather + un-tiling incl. waiting for the slowest rank) from HIP events, and the roofline object of rank 0's kernel."""
+    import hashlib
+
+    import torch
+
+    import srt_amd
+    from soft_rendering_toolsets_amd import scenes
+
+    W = H = args.size
+    spp = args.spp_per_step
+    steps = max(2, min(args.steps, 8))
+    scene = scenes.cornell_with_mesh(7, "glass") if args.scene == "cfg5" else scenes.cornell_box(args.scene)
+    ndev = torch.cuda.device_count()
+    rows, base_sha = [], None
+    for n in [int(x) for x in args.group.split(",")]:
+        devices = list(range(n)) if ndev >= n else [0] * n
+        grp = srt_amd.PathtracerGroup(devices)
+        grp.set_params(W, H, spp * steps, args.depth, True)
+        grp.build_scene(scene)
+        grp.set_camera(scene["camera"])
+        grp.render_epoch_device(args.seed, 0, spp)                 # warm-up: scratch exists before the clock starts
+        torch.cuda.synchronize()
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        grp.ray_count(reset=True)
+        for m in grp.members:
+            m.kernel_time(enable=True)
+        grp.gather_time(enable=True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            d_img, stream = grp.render_epoch_device(args.seed, i * spp, spp)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        elapsed = time.perf_counter() - t0
+        rays, cams = grp.ray_count(reset=True)
+        kms = [m.kernel_time(enable=False) for m in grp.members]
+        gms, gn = grp.gather_time(enable=False)
+        img = grp.render_epoch(args.seed, 0, spp)                   # the epoch image of sample 0.. (host copy) for the hash
+        sha = hashlib.sha256(img.tobytes()).hexdigest()[:16]
+        base_sha = base_sha or sha
+        # rank 0's kernel against the issue ceiling / SURVEY.md 8(d)'s byte figure, as in the headline (counters only at N = 1)
+        rng = np.random.default_rng(1)
+        k = 1 << 14
+        xs, ys = rng.integers(0, W, k).astype(np.uint32), rng.integers(0, H, k).astype(np.uint32)
+        grp.members[0].set_tiling(32, 32, 0, 1)
+        grp.members[0].trace_samples(args.seed, xs, ys, rng.integers(0, spp, k).astype(np.uint32))
+        cnt = grp.members[0].counters()
+        doc, why_not = profile_doc(args.scene, W, spp, 1) if n == 1 else (None, "the committed counter passes are one-GPU runs")
+        rank0_ms = kms[0][0] / max(1, kms[0][1])
+        scratch, _ = ray_state_bytes(rays / steps / n, cams / steps / n)
+        rows.append({
+            "n_ranks": n, "devices": devices, "distinct_devices": len(set(devices)), "uses_rccl": grp.uses_rccl(),
+            "rehearsal_on_one_gpu": len(set(devices)) < n,
+            "ms_per_step": elapsed * 1e3 / steps, "value": rays / elapsed / 1e6, "unit": "Mrays/s", "steps": steps,
+            "image_sha256_16": sha, "image_equals_n1": sha == base_sha,
+            "rank_kernel_ms": [t / max(1, c) for t, c in kms], "exchange_ms": gms / max(1, gn),
+            "roofline": pt_roofline(cnt, rays / steps / n, rank0_ms, doc, why_not, "rank 0's dominant kernel", scratch),
+        })
+        grp.close()
+    return rows
 
 
 def main():
@@ -424,7 +574,14 @@ def main():
     ap.add_argument("--no-raster", action="store_true")
     ap.add_argument("--no-elision", action="store_true", help="skip the extra pass that measures dead-ray elision")
     ap.add_argument("--no-overlap", action="store_true", help="every step on one stream (no overlap of consecutive launches)")
+    ap.add_argument("--group", default=None, metavar="N[,M..]",
+                    help="time the in-process multi-GPU path (srt_pt_create_multi: what the C++ drop-in uses) for these rank counts and print "
+                         "one JSON line {\"group\": [...]}; ranks share device 0 where the box has fewer GPUs (a rehearsal, labelled)")
     args = ap.parse_args()
+    if args.group:
+        print(json.dumps({"metric": "Mrays/s", "mode": "in-process group (srt_pt_group_render_epoch_device)", "scene": args.scene,
+                          "group": group_bench(args)}), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -532,9 +689,21 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays, cams = pt.ray_count()
+    # the same steps on ONE stream: a step on its own, wall clock (the timed region above overlaps consecutive launches on two streams)
+    no_overlap_ms = None
+    if nstreams > 1 and world == 1:
+        pt.ray_count(reset=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            pt.render_epoch_device(streams[0].cuda_stream, args.seed, i * spp, spp, tiles[0].data_ptr())
+        torch.cuda.synchronize()
+        no_overlap_ms = (time.perf_counter() - t1) * 1e3 / args.steps
     pt.kernel_time(enable=True)
+    sc = None
     if form >= 3:
         pt.stream_times(enable=True)
+        pt.stream_counters(reset=True)
     # the dominant kernel on its own (HIP events inside the library, on the launch stream): two launches after the
     # timed region, nothing else in flight - inside the timed region consecutive launches overlap by design
     for j in range(2):
@@ -547,6 +716,8 @@ def main():
         ms3, gens = pt.stream_times(enable=False)
         stream_split = {k: v / 2 for k, v in ms3.items()}
         stream_split["generations_enqueued_per_step"] = gens // 2
+        sc = pt.stream_counters(reset=True)
+        sc["entries_queued"] //= 2; sc["alive_slot_generations"] //= 2        # (two launches were counted)
     pt.ray_count(reset=True)
     epoch_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))  # per step, overlapped
     if world > 1:
@@ -611,13 +782,11 @@ def main():
         prof_doc, why_not = profile_doc(args.scene, W, spp, world)
         # ray state that goes through memory per launch (SURVEY.md 8(d)'s last term): a 32-byte record per shaded bounce,
         # written once and read once, and one 16-byte store per sample (read again by the ordered reduction)
-        bounces = max(0.0, (rays_per_launch_rank0 - cams_per_launch_rank0) / 3.0)
-        scratch = 64.0 * bounces + 32.0 * cams_per_launch_rank0
-        if form >= 3:    # the streamed forms also keep the path state, the rays / walk requests and the hits in memory between two kernels
-            scratch += (rays_per_launch_rank0 / 2.8) * 2 * 24 * 4 + rays_per_launch_rank0 * (2 * 36 + 2 * 8)
+        scratch, scratch_terms = ray_state_bytes(rays_per_launch_rank0, cams_per_launch_rank0, sc)
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step_no_overlap": no_overlap_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": (f"Scotty3D Pathtracer: Cornell box + 131 072-triangle glass mesh + mirror sphere (BASELINE configs[4]; seeded procedural "
@@ -626,7 +795,8 @@ def main():
                             (f"Scotty3D Pathtracer: Cornell box ({args.scene}: area light + MIS"
                              f"{', mirror + glass spheres' if args.scene == 'cbox' else ''}), {W}x{H}, {spp} spp per step "
                              f"({args.steps} steps = {spp * args.steps} spp; 32 steps = BASELINE configs[3] 2048 spp), depth {args.depth}, BVH on"),
-                "tiles": "32x32 round-robin over ranks", "collective": "one RCCL gather of tile radiance per step" if world > 1 else "none (1 GPU)",
+                "tiles": "32x32 round-robin over ranks", "collective": ("one gloo gather of tile radiance per step (rehearsal: N ranks on one GPU, never a reported number)" if rehearse else
+                               "one RCCL gather of tile radiance per step") if world > 1 else "none (1 GPU)",
                 "seed": args.seed,
             },
             "camera_samples_per_s": total_cams / elapsed, "rays": total_rays, "camera_samples": total_cams,
@@ -638,7 +808,7 @@ def main():
                 "kernel_ms_is": "one launch on its own, after the timed region (the streamed forms: every kernel of one epoch); "
                                 "`ms_per_step` is wall time of the timed region / steps, where consecutive launches overlap on two streams",
                 "step_span_ms_on_its_stream": epoch_ms,   # start-to-end of a step on its own stream; the other stream's step shares the GPU meanwhile
-                "stream_kernels_ms": stream_split,
+                "stream_kernels_ms": stream_split, "ray_state_terms": scratch_terms,
             }),
         }
         if elision is not None:

@@ -93,6 +93,11 @@ int srt_pt_group_set_params(srt_pt_group* g, uint32_t width, uint32_t height, ui
 int srt_pt_group_render_epoch(srt_pt_group* g, uint64_t seed, uint32_t sample_base, uint32_t samples, float* rgb_out);
 int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sample_base, uint32_t samples, float** d_image_out,
                                      void** stream_out);
+/* Device time of the exchange step of srt_pt_group_render_epoch[_device] - from the moment rank 0's own tiles are rendered to the end of
+ * the un-tiling kernel on rank 0's stream: the gather (RCCL, or copies between ranks that share a device) and what it waits for, i.e. the
+ * slowest other rank - summed over the epochs since the previous call (HIP events; waits for them); then recording on / off.  A diagnostic
+ * for bench.py --group: together with the members' srt_pt_kernel_time it decomposes a multi-GPU step. */
+int srt_pt_group_gather_time(srt_pt_group* g, int enable, double* total_ms, uint64_t* epochs);
 
 /* ---- build_scene ---------------------------------------------------------------------------- */
 int srt_pt_scene_begin(srt_pt* pt);
@@ -142,7 +147,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh);
  * environment forces the host build. */
 int srt_pt_set_bvh_builder(srt_pt* pt, int device, uint32_t min_primitives);
 /* The streamed forms (kernel modes 6 / 7, what auto takes for scenes with a real BVH<Triangle> or many objects) keep this many
- * paths in flight per launch (rounded up to 256; 0 = the default, 2 Mi; at most 2^26, SRT_ERR_INVALID beyond; ~1 KB of device
+ * paths in flight per launch (rounded up to 256; 0 = the default, 3 Mi; at most 2^26, SRT_ERR_INVALID beyond; ~1 KB of device
  * memory per slot).  The image does not depend on it. */
 int srt_pt_set_stream_slots(srt_pt* pt, uint32_t slots);
 
@@ -206,6 +211,11 @@ int srt_pt_kernel_time(srt_pt* pt, int enable, double* total_ms, uint64_t* launc
  * the previous call (HIP events around each launch, on the launch stream; waits for them), and the number of generations
  * enqueued; then switches recording on (enable != 0) or off.  Off by default: a diagnostic. */
 int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[4], uint64_t* generations);
+/* Streamed forms only: {entries queued to the ray-cast kernel, alive path-slot generations} summed over every generation of every launch since
+ * the last reset (device counters of the compaction kernel; waits for the device), and the bytes the forms move through memory per alive
+ * slot-generation (saved path state, both logic kernels) and per queued entry (ray planes, list entry, hit) as the kernels' layout has them.
+ * bench.py prices the "ray state" term of SURVEY.md 8(d)'s byte figure with these. */
+int srt_pt_stream_counters(srt_pt* pt, uint64_t out[4], int reset);
 /* Which form render_epoch* takes for the committed scene under the current kernel mode: 0 persistent wave kernel with sweeps,
  * 1 the same with inline BVH<Triangle> walks, 2 persistent waves with the flattened walk, 3 streamed (every ray through the
  * ray-cast kernel), 4 streamed sweeps (BVH<Triangle> walks queued), -1 lane per sample, -2 lane per pixel. */

@@ -11,6 +11,7 @@
 // (auto_adjust, :476-483), resize lends the framebuffer (:107-123), '=' raises the sample rate (:417-432), redraw clears
 // through the BASE-class pointer, sets svg_2_screen and calls draw_svg (:435-455).  The renderer is only ever touched
 // through a SoftwareRenderer*, as the application does.
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -74,6 +75,66 @@ int dropin_raster_session(const char* path, int device, uint32_t w, uint32_t h, 
     Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
     software_renderer->set_svg_2_screen(m_imp);
     software_renderer->draw_svg(*svg);
+  }
+  std::memcpy(rgba_out, framebuffer.data(), framebuffer.size());
+  delete static_cast<SoftwareRendererHIP*>(software_renderer);
+  return 0;
+}
+
+// Wall time of DrawSVG's redraw through the drop-in class - what SURVEY.md 8(d) calls the `draw_svg` wall, for bench.py.
+// The session is set up as in dropin_raster_session; then `frames` redraws are timed twice:
+//   ms_out[0]  the view moves every frame (the viewbox is nudged, as a pan does): stream build on the host, upload, setup,
+//              binning, tiles, resolve and the read-back into DrawSVG's framebuffer
+//   ms_out[1]  the view stays (an expose / key event): the stream is rebuilt and found unchanged, the tile kernel and the
+//              read-back remain
+//   ms_out[2]  of ms_out[0], the host's share: SvgStreamBuilder::build alone (element walk, transforms, triangulation)
+// rgba_out (w*h*4) receives the framebuffer after a final redraw in the ORIGINAL view (the golden's).
+int dropin_raster_bench(const char* path, int device, uint32_t w, uint32_t h, uint32_t sample_rate, uint32_t frames, double ms_out[3],
+                        uint8_t* rgba_out) {
+  SVG* svg = new SVG();
+  if (SVGParser::load(path, svg) < 0) return -1;
+  SoftwareRenderer* software_renderer = new SoftwareRendererHIP(device);
+  Sampler2DImp* sampler = new Sampler2DImp();
+  software_renderer->set_tex_sampler(sampler);
+  std::vector<Image*> images;
+  for (size_t i = 0; i < svg->elements.size(); ++i) collect_images(svg->elements[i], images);
+  for (Image* im : images) sampler->generate_mips(im->tex, 0);
+  ViewportImp* viewport = new ViewportImp();
+  const float sw = svg->width, sh = svg->height;
+  const float span = 1.2 * std::max(sw, sh) / 2;
+  viewport->set_viewbox(sw / 2, sh / 2, span);
+  std::vector<unsigned char> framebuffer(4 * (size_t)w * h);
+  software_renderer->set_render_target(&framebuffer[0], w, h);
+  Matrix3x3 norm_to_screen = Matrix3x3::identity();
+  float scale = std::min(w, h);
+  norm_to_screen(0, 0) = scale; norm_to_screen(0, 2) = (w - scale) / 2;
+  norm_to_screen(1, 1) = scale; norm_to_screen(1, 2) = (h - scale) / 2;
+  for (size_t rate = 2; rate <= sample_rate; rate++) software_renderer->set_sample_rate(rate);
+  auto redraw = [&]() {
+    software_renderer->clear_target();
+    Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
+    software_renderer->set_svg_2_screen(m_imp);
+    software_renderer->draw_svg(*svg);
+  };
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int k = 0; k < 3; k++) redraw();
+  double t = now();
+  for (uint32_t k = 0; k < frames; k++) {
+    viewport->set_viewbox(sw / 2 + 0.37f * (float)(k % 5), sh / 2 - 0.21f * (float)(k % 3), span);   // a pan of a fraction of a pixel per frame
+    redraw();
+  }
+  ms_out[0] = (now() - t) / frames;
+  viewport->set_viewbox(sw / 2, sh / 2, span);
+  redraw();
+  t = now();
+  for (uint32_t k = 0; k < frames; k++) redraw();
+  ms_out[1] = (now() - t) / frames;
+  {
+    SvgStreamBuilder builder;
+    Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
+    t = now();
+    for (uint32_t k = 0; k < frames; k++) builder.build(*svg, m_imp, sample_rate);
+    ms_out[2] = (now() - t) / frames;
   }
   std::memcpy(rgba_out, framebuffer.data(), framebuffer.size());
   delete static_cast<SoftwareRendererHIP*>(software_renderer);

@@ -29,6 +29,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_group_set_params.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32]
     lib.srt_pt_group_render_epoch.argtypes = [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]
     lib.srt_pt_group_render_epoch_device.argtypes = [c_void_p, c_uint64, c_uint32, c_uint32, POINTER(c_void_p), POINTER(c_void_p)]
+    lib.srt_pt_group_gather_time.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]
     lib.srt_pt_destroy.argtypes = [c_void_p]
     lib.srt_pt_scene_begin.argtypes = [c_void_p]
     lib.srt_pt_add_material.argtypes = [c_void_p, POINTER(PtMaterial), POINTER(c_uint32)]
@@ -54,6 +55,7 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_kernel_time.argtypes = [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]
     lib.srt_pt_ray_count.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), c_int]
     lib.srt_pt_stream_times.argtypes = [c_void_p, c_int, c_void_p, POINTER(c_uint64)]
+    lib.srt_pt_stream_counters.argtypes = [c_void_p, c_void_p, c_int]
     lib.srt_pt_kernel_form.argtypes = [c_void_p, POINTER(c_int)]
     lib.srt_pt_trace_samples.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]
     lib.srt_pt_hit.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
@@ -281,6 +283,13 @@ class Pathtracer:
         self._check(self._lib, self._lib.srt_pt_stream_times(self._ctx, int(enable), _p(ms), ctypes.byref(g)))
         return {"logic_ms": float(ms[0]), "compact_ms": float(ms[1]), "cast_ms": float(ms[2]), "probe_ms": float(ms[3])}, int(g.value)
 
+    def stream_counters(self, reset: bool = False) -> dict:
+        """Streamed forms: entries queued to the ray-cast kernel and alive path-slot generations since the last reset, and the bytes per unit."""
+        out = np.zeros(4, np.uint64)
+        self._check(self._lib, self._lib.srt_pt_stream_counters(self._ctx, _p(out), int(reset)))
+        return {"entries_queued": int(out[0]), "alive_slot_generations": int(out[1]), "bytes_per_alive_slot_generation": int(out[2]),
+                "bytes_per_queued_entry": int(out[3])}
+
     def kernel_form(self) -> int:
         """Form render_epoch takes for the committed scene: 0 / 1 persistent sweeps (1: inline mesh walks), 2 flattened walk,
         3 streamed, 4 streamed sweeps, -1 lane per sample, -2 lane per pixel."""
@@ -436,6 +445,18 @@ class PathtracerGroup:
         out = np.zeros((self.out_h, self.out_w, 3), np.float32)
         self._check(self._lib, self._lib.srt_pt_group_render_epoch(self._g, seed, sample_base, samples, _p(out)))
         return out
+
+    def render_epoch_device(self, seed: int, sample_base: int, samples: int):
+        """Enqueue one epoch on every rank + the gather; returns (device pointer of the image on rank 0, its stream). No wait."""
+        d, s = c_void_p(), c_void_p()
+        self._check(self._lib, self._lib.srt_pt_group_render_epoch_device(self._g, seed, sample_base, samples, ctypes.byref(d), ctypes.byref(s)))
+        return d.value, s.value
+
+    def gather_time(self, enable: bool = True):
+        """(total ms, epochs) of the exchange step (gather + un-tiling, incl. waiting for the slowest rank) since the previous call."""
+        ms, n = ctypes.c_double(), c_uint64()
+        self._check(self._lib, self._lib.srt_pt_group_gather_time(self._g, int(enable), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def ray_count(self, reset: bool = False):
         r = [m.ray_count(reset) for m in self.members]

@@ -341,7 +341,7 @@ struct srt_pt {
   int bvh_builder = 1; uint32_t bvh_device_min = 16384;         // srt_pt_set_bvh_builder: device build for sets of >= this many primitives
   uint32_t stream_slots = 0;                                    // srt_pt_set_stream_slots (0: default)
   unsigned long long* d_cast_stats = nullptr;                   // SRT_CAST_STATS=1: the STATS build of pt_cast_kernel adds into these
-  unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 2 slots: rays of the epoch kernels, rays elided
+  unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 4 slots: rays of the epoch kernels, rays elided, streamed forms: entries queued, alive slot-generations
   uint32_t* h_fault = nullptr;              // pinned, device-visible: bit 0 = a streamed launch ended with unfinished units (sticky until reported)
   uint32_t* d_fault = nullptr;              // its device address
   int elide = 0;                            // srt_pt_set_elision
@@ -713,7 +713,10 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     P.units3 = px * P.groups3;
     P.total_units = px * (P.groups3 + P.singles);
     // path slots: every unit its own while they are few, else a fixed population that is refilled from the unit queue
-    uint64_t want_slots = pt->stream_slots ? pt->stream_slots : (1u << 21);
+    // (default 3 Mi slots: with the logic split in two kernels the ray-cast kernel's gain from a larger population - fewer, fuller
+    //  generations: 133 -> 119 ms per epoch of BASELINE configs[4]'s stand-in - outweighs what the logic kernels lose once their state
+    //  outgrows the Infinity Cache; 2 Mi: 188.9, 3 Mi: 183.1, 4 Mi: 184.7, 8 Mi: 201.9 ms per epoch)
+    uint64_t want_slots = pt->stream_slots ? pt->stream_slots : (3u << 20);
     if (!pt->stream_slots && getenv("SRT_STREAM_SLOTS")) {    // diagnostic override; anything outside [1, kMaxStreamSlots] is ignored
       const long long v = atoll(getenv("SRT_STREAM_SLOTS"));
       if (v >= 1 && v <= (long long)kMaxStreamSlots) want_slots = (uint64_t)v;
@@ -790,7 +793,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
 #undef SRT_LAUNCH_LOGIC
 #undef SRT_LAUNCH_PHASE
         if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 1)) != SRT_OK) return st;
-        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id);
+        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id, pt->d_totals + C_COUNT + 2);
         if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
         C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
         const dim3 kgrid(pt->cast_blocks), kblock(pt->cast_threads);
@@ -857,10 +860,10 @@ int srt_pt_create(int device, srt_pt** out) {
     }
     if (device >= count) { delete pt; return srt::fail(SRT_ERR_INVALID, "device %d out of range [0,%d)", device, count); }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pt->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&pt->d_totals, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&pt->d_totals, (C_COUNT + 4) * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void**)&pt->h_fault, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&pt->d_fault, pt->h_fault, 0) != hipSuccess ||
-        hipMemset(pt->d_totals, 0, (C_COUNT + 2) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(pt->d_totals, 0, (C_COUNT + 4) * sizeof(unsigned long long)) != hipSuccess) {
       delete pt;
       return srt::fail(SRT_ERR_HIP, "HIP context setup failed on device %d", device);
     }
@@ -1253,6 +1256,24 @@ int srt_pt_stream_times(srt_pt* pt, int enable, double ms_out[4], uint64_t* gene
   if (generations) *generations = pt->stream_generations;
   pt->stream_generations = 0;
   pt->stream_timing = enable != 0;
+  return SRT_OK;
+}
+
+int srt_pt_stream_counters(srt_pt* pt, uint64_t out[4], int reset) {
+  int st = need_device(pt, "srt_pt_stream_counters");
+  if (st != SRT_OK) return st;
+  if (!out) return srt::fail(SRT_ERR_INVALID, "srt_pt_stream_counters: out is NULL");
+  SRT_HIP(hipDeviceSynchronize());
+  unsigned long long h[2] = {0, 0};
+  SRT_HIP(hipMemcpy(h, pt->d_totals + C_COUNT + 2, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h[0]; out[1] = h[1];
+  // Bytes the streamed forms move through memory per unit, from the layout in pt_wave.h / pt_stream.h (three-ray batches):
+  //   per alive slot and generation: the resolve kernel loads and stores the flags word and 27 state words (28 + 28), the probe kernel
+  //   loads the flags and the 14 words of the batch's rays and stores the emit word (15 + 1), the compaction reads the emit word (1)
+  //   per queued entry: origin + direction planes (2 x 16 B) and the list entry (4 B) written and read once each, the hit (8 B) written and read
+  out[2] = (28u + 28u + 15u + 1u + 1u) * 4u;
+  out[3] = (32u + 4u + 8u) * 2u;
+  if (reset) SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 2, 0, sizeof h));
   return SRT_OK;
 }
 

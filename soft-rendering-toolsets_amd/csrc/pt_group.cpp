@@ -69,6 +69,9 @@ struct srt_pt_group {
   Rccl rccl;
   std::vector<ncclComm_t> comms;
   uint32_t tile_w = 32, tile_h = 32;
+  // srt_pt_group_gather_time: event pairs on rank 0's stream around the gather + un-tiling of each epoch
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, spare;
 };
 
 namespace {
@@ -152,6 +155,8 @@ int srt_pt_group_destroy(srt_pt_group* g) {
     for (ncclComm_t c : g->comms)
       if (c) (void)g->rccl.CommDestroy(c);
   free_buffers(g);
+  for (auto* v : {&g->timed, &g->spare})
+    for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (size_t r = 0; r < g->ctx.size(); r++) {
     (void)hipSetDevice(g->devices[r]);
     if (g->events[r]) (void)hipEventDestroy(g->events[r]);
@@ -190,6 +195,14 @@ int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sa
     if ((st = srt_pt_render_epoch_device(g->ctx[r], (void*)g->streams[r], seed, sample_base, samples, g->d_tiles[r])) != SRT_OK) return st;
   }
   const float* gathered = g->d_tiles[0];
+  if (g->timing) {                       // (the bracket opens once rank 0's own tiles are rendered: what follows is exchange + un-tiling)
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    SRT_HIP(hipSetDevice(g->devices[0]));
+    if (!g->spare.empty()) { ev = g->spare.back(); g->spare.pop_back(); }
+    else { SRT_HIP(hipEventCreate(&ev.first)); SRT_HIP(hipEventCreate(&ev.second)); }
+    g->timed.push_back(ev);
+    SRT_HIP(hipEventRecord(ev.first, g->streams[0]));
+  }
   if (g->use_rccl) {                     // ONE collective per epoch: tile radiance -> rank 0
     // (no early return between GroupStart and GroupEnd: a failing rank ends the loop, the group is always closed)
     ncclResult_t rc = g->rccl.GroupStart();
@@ -219,6 +232,7 @@ int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sa
   }
   SRT_HIP(hipSetDevice(g->devices[0]));
   if ((st = srt_pt_untile_device(g->ctx[0], (void*)g->streams[0], gathered, g->d_image)) != SRT_OK) return st;
+  if (g->timing) SRT_HIP(hipEventRecord(g->timed.back().second, g->streams[0]));
   if (n > 1 && !g->use_rccl) {
     // the next epoch must not overwrite a rank's tiles before rank 0 has copied them
     SRT_HIP(hipEventRecord(g->events[0], g->streams[0]));
@@ -227,6 +241,25 @@ int srt_pt_group_render_epoch_device(srt_pt_group* g, uint64_t seed, uint32_t sa
   }
   if (d_image_out) *d_image_out = g->d_image;
   if (stream_out) *stream_out = (void*)g->streams[0];
+  return SRT_OK;
+}
+
+int srt_pt_group_gather_time(srt_pt_group* g, int enable, double* total_ms, uint64_t* epochs) {
+  if (!g) return srt::fail(SRT_ERR_INVALID, "srt_pt_group_gather_time: NULL group");
+  SRT_HIP(hipSetDevice(g->devices[0]));
+  double sum = 0.0;
+  uint64_t n = 0;
+  for (auto& ev : g->timed) {
+    SRT_HIP(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    SRT_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+    sum += ms; n++;
+    g->spare.push_back(ev);
+  }
+  g->timed.clear();
+  g->timing = enable != 0;
+  if (total_ms) *total_ms = sum;
+  if (epochs) *epochs = n;
   return SRT_OK;
 }
 

@@ -137,23 +137,29 @@ struct CastParams {
 // Dense list of the queue positions that carry a ray: the logic kernel left one mask word per path slot (bit q: queue slot
 // q); a block takes kCompactChunk consecutive path slots and appends its positions with ONE atomic.
 constexpr uint32_t kCompactChunk = 8192;
+// `totals` (optional): {entries queued, alive slot-generations} summed over every generation of every launch - what bench.py prices the
+// streamed forms' ray-state traffic with (srt_pt_stream_counters).
 __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __restrict__ emit, uint32_t nlanes, uint32_t nslots,
-                                                          StreamCounters* sc, uint32_t gen, uint32_t* __restrict__ ray_id) {
+                                                          StreamCounters* sc, uint32_t gen, uint32_t* __restrict__ ray_id,
+                                                          unsigned long long* __restrict__ totals) {
   if (sc->done != 0u) return;
   __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_live[16];
   __shared__ uint32_t s_base;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t first = blockIdx.x * kCompactChunk;
   constexpr uint32_t kPer = kCompactChunk / 1024u;
-  uint32_t m[kPer], n = 0;
+  uint32_t m[kPer], n = 0, live = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kPer; k++) {
     const uint32_t slot = first + k * 1024u + threadIdx.x;
     m[k] = slot < nlanes ? emit[slot] : 0u;
-    if (m[k] & 0x80000000u) sc->alive[gen & 1u] = 1u;     // (every writer stores the same value)
+    if (m[k] & 0x80000000u) { sc->alive[gen & 1u] = 1u; live++; }     // (every writer stores the same value)
     m[k] &= 0x7fffffffu;
     n += (uint32_t)__popc(m[k]);
   }
+  for (int off = 32; off > 0; off >>= 1) live += (uint32_t)__shfl_down((int)live, off);
+  if (lane == 0u) s_live[wave] = live;                    // (one global atomic per block, below: a single word takes ~90 of them per microsecond)
   uint32_t incl = n;                                      // inclusive scan over the wave, then over the block's waves
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += v; }
@@ -163,6 +169,12 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __rest
     uint32_t total = 0;
     for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
     s_base = total ? atomicAdd(&sc->nrays[gen & 1u], total) : 0u;
+    if (totals) {
+      uint32_t alive_slots = 0;
+      for (uint32_t w = 0; w < 16u; w++) alive_slots += s_live[w];
+      if (total) atomicAdd(&totals[0], (unsigned long long)total);
+      if (alive_slots) atomicAdd(&totals[1], (unsigned long long)alive_slots);
+    }
   }
   __syncthreads();
   uint32_t at = s_base + s_wave[wave] + incl - n;

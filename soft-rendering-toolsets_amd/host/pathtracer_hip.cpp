@@ -106,9 +106,9 @@ void Pathtracer::feed_scene(srt_pt* ctx, Scene& layout_scene) {
             if(obj.is_shape()) {
                 const float radius = obj.opt.shape.get<PT::Sphere>().radius;
                 if(is_light) {
-                    // The reference lights a shape through its triangle approximation (area_lights gets
-                    // Tri_Mesh(obj.posed_mesh(), false)) but intersects the analytic shape.
-                    const GL::Mesh& mesh = obj.posed_mesh();
+                    // The reference lights a shape through its triangle approximation - area_lights gets
+                    // Tri_Mesh(obj.opt.shape.mesh(), false), rays/pathtracer.cpp:110-111 - but intersects the analytic shape.
+                    const GL::Mesh mesh = obj.opt.shape.mesh();
                     std::vector<float> pos, nrm;
                     for(const auto& v : mesh.verts()) {
                         pos.insert(pos.end(), {v.pos.x, v.pos.y, v.pos.z});

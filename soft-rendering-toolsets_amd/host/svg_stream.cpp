@@ -99,8 +99,10 @@ void SvgStreamBuilder::walk(SVGElement* e) {
       Polygon& pg = static_cast<Polygon&>(*e);
       Color c = pg.style.fillColor;
       if (c.a != 0) {
-        std::vector<Vector2D> tris;
-        triangulate(pg, tris);
+        // triangulate() depends on the polygon's own points only, not on the view: a redraw after a pan or zoom reuses the list
+        // (the reference ear-clips again every frame; for BASELINE configs[1] that is 2.8 ms of a 3.2 ms redraw).  The cache entry
+        // is checked against the points themselves, so an edited polygon is triangulated again.
+        const std::vector<Vector2D>& tris = triangulation_of(pg);
         for (size_t i = 0; i + 2 < tris.size(); i += 3) {
           Vector2D p0 = transform(tris[i]);
           Vector2D p1 = transform(tris[i + 1]);
@@ -137,6 +139,19 @@ void SvgStreamBuilder::walk(SVGElement* e) {
   }
 
   transformation = transformation * e->transform.inv();
+}
+
+const std::vector<Vector2D>& SvgStreamBuilder::triangulation_of(const Polygon& pg) {
+  CachedTriangulation& c = tri_cache_[&pg];
+  bool same = c.valid && c.points.size() == pg.points.size();
+  for (size_t i = 0; same && i < pg.points.size(); i++) same = c.points[i].x == pg.points[i].x && c.points[i].y == pg.points[i].y;
+  if (!same) {
+    c.points = pg.points;
+    c.tris.clear();
+    triangulate(pg, c.tris);
+    c.valid = true;
+  }
+  return c.tris;
 }
 
 void SvgStreamBuilder::emit_triangle(float x0, float y0, float x1, float y1, float x2, float y2,

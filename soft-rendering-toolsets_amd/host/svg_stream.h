@@ -6,6 +6,7 @@
 #ifndef SRT_SVG_STREAM_H
 #define SRT_SVG_STREAM_H
 
+#include <map>
 #include <vector>
 
 #include "svg_renderer.h"  // the reference's SVGRenderer (transform stack helpers)
@@ -36,6 +37,11 @@ class SvgStreamBuilder : public SVGRenderer {
   void emit_point(double x, double y, const Color& c);
   void emit_line(float x0, float y0, float x1, float y1, Color c);
   void emit_image(float x0, float y0, float x1, float y1, const Texture& tex);
+
+  // triangulate() results per polygon element, valid while the polygon's points are what they were (see walk())
+  struct CachedTriangulation { bool valid; std::vector<Vector2D> points, tris; CachedTriangulation() : valid(false) {} };
+  const std::vector<Vector2D>& triangulation_of(const Polygon& pg);
+  std::map<const Polygon*, CachedTriangulation> tri_cache_;
 
   size_t sample_rate_;
   std::vector<srt_prim> stream_;

@@ -11,11 +11,18 @@ out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 if [ "$scene" = raster ]; then
-  # the rasterizer on BASELINE configs[1]: kernel trace + two SQ counter passes over tools/raster_bench.py
+  # the rasterizer on BASELINE configs[1] and on the stress frame: kernel trace, two SQ counter passes, FETCH_SIZE, WRITE_SIZE (+ L2 hit / miss)
+  # over tools/raster_bench.py (full frames of the resident stream)
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 100 > "$out/stats.log" 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$out/a" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 20 > "$out/a.log" 2>&1
-  rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU --output-format csv -d "$out/b" -- python3 "$root/tools/raster_bench.py" raster_cfg2_test3_1024_ss4.npz 20 > "$out/b.log" 2>&1
+  for wl in cfg2 stress; do
+    if [ $wl = cfg2 ]; then fx=raster_cfg2_test3_1024_ss4.npz; n=100; m=20; else fx=stress_degenerate2_1024_ss4.npz; n=20; m=5; fi
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${wl}_stats" -- python3 "$root/tools/raster_bench.py" $fx $n > "$out/${wl}_stats.log" 2>&1
+    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d "$out/${wl}_a" -- python3 "$root/tools/raster_bench.py" $fx $m > "$out/${wl}_a.log" 2>&1
+    rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU --output-format csv -d "$out/${wl}_b" -- python3 "$root/tools/raster_bench.py" $fx $m > "$out/${wl}_b.log" 2>&1
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${wl}_fetch" -- python3 "$root/tools/raster_bench.py" $fx $m > "$out/${wl}_fetch.log" 2>&1
+    rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/${wl}_write" -- python3 "$root/tools/raster_bench.py" $fx $m > "$out/${wl}_write.log" 2>&1
+    echo "$wl passes done"
+  done
   cd "$root"
   python3 tools/make_raster_profile.py "$out" "$tag"
   exit 0

@@ -1,5 +1,7 @@
 """Reduce the rocprofv3 passes of `tools/collect_profiles.sh <tag> raster` to profiles/<tag>_raster.json: per-frame means of the
-SQ counters of raster_tiles (and the binning passes) on BASELINE configs[1], stamped with the kernel-source digest."""
+SQ counters and of the memory-side traffic (FETCH_SIZE, WRITE_SIZE; units and the gfx950 correction as MI355X_MICROARCH.md says:
+both in KB, FETCH_SIZE doubled) of the tile kernel on BASELINE configs[1] ("cfg2") and on SURVEY.md 8(d)'s stress frame ("stress"),
+plus the kernel trace's average durations, stamped with the kernel-source digest."""
 import csv
 import glob
 import json
@@ -30,28 +32,44 @@ def per_dispatch(path, kernel_substr):
     return {c: sums[c] / calls[c] for c in sums}
 
 
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
+
+
 def main():
     out, tag = sys.argv[1], sys.argv[2]
     from bench import kernel_source_sha
 
     os.makedirs("profiles", exist_ok=True)
-    stats = find(out, "stats", "kernel_stats.csv")
-    shutil.copy(stats, f"profiles/{tag}_raster_kernel_stats.csv")
-    kernels = {}
-    with open(stats, newline="") as fh:
-        for row in csv.DictReader(fh):
-            if "raster_" in row["Name"]:
-                kernels[row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
-    tiles, bins = {}, {}
-    for sub in ("a", "b"):
-        path = find(out, sub, "counter_collection.csv")
-        shutil.copy(path, f"profiles/{tag}_raster_pmc_{sub}.csv")
-        tiles.update(per_dispatch(path, "raster_tiles<false"))
-        bins.update({k: v for k, v in per_dispatch(path, "raster_bin_pass<1>").items()})
-    doc = {"workload": {"scene": "raster_cfg2", "svg": "basic/test3.svg", "size": 1024, "sample_rate": 4},
-           "kernel_source_sha16": kernel_source_sha(), "kernels": kernels, "raster_tiles_per_frame": tiles, "bin_pass1_per_frame": bins,
-           "method": "rocprofv3 --kernel-trace --stats and two --pmc passes (SQ counters) of tools/raster_bench.py raster_cfg2_test3_1024_ss4.npz 100; "
-                     "per-dispatch means of raster_tiles<false, 16>"}
+    doc = {"kernel_source_sha16": kernel_source_sha(),
+           "method": "per workload: rocprofv3 --kernel-trace --stats, two --pmc passes of SQ counters, --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum "
+                     "TCC_MISS_sum (separate runs, never combined with a trace) of tools/raster_bench.py <fixture> <frames> - full frames (setup + binning + "
+                     "tiles) of the resident stream; per-dispatch means of raster_tiles<false, ..>; FETCH_SIZE / WRITE_SIZE are KB, FETCH_SIZE doubled (gfx950)"}
+    for wl, fixture in (("cfg2", "raster_cfg2_test3_1024_ss4.npz"), ("stress", "stress_degenerate2_1024_ss4.npz")):
+        stats = find(out, f"{wl}_stats", "kernel_stats.csv")
+        shutil.copy(stats, f"profiles/{tag}_raster_{wl}_kernel_stats.csv")
+        kernels = {}
+        with open(stats, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if "raster_" in row["Name"]:
+                    kernels[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
+        tiles = {}
+        for sub in ("a", "b"):
+            path = find(out, f"{wl}_{sub}", "counter_collection.csv")
+            shutil.copy(path, f"profiles/{tag}_raster_{wl}_pmc_{sub}.csv")
+            tiles.update(per_dispatch(path, "raster_tiles<false"))
+        traffic = None
+        try:
+            f = per_dispatch(find(out, f"{wl}_fetch", "counter_collection.csv"), "raster_tiles<false")
+            w = per_dispatch(find(out, f"{wl}_write", "counter_collection.csv"), "raster_tiles<false")
+            shutil.copy(find(out, f"{wl}_fetch", "counter_collection.csv"), f"profiles/{tag}_raster_{wl}_pmc_fetch_size.csv")
+            shutil.copy(find(out, f"{wl}_write", "counter_collection.csv"), f"profiles/{tag}_raster_{wl}_pmc_write_size_l2.csv")
+            rd, wr = f["FETCH_SIZE"] * 1024 * 2, w["WRITE_SIZE"] * 1024
+            traffic = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "FETCH_SIZE_KB": f["FETCH_SIZE"], "WRITE_SIZE_KB": w["WRITE_SIZE"],
+                       "TCC_HIT_sum": w.get("TCC_HIT_sum"), "TCC_MISS_sum": w.get("TCC_MISS_sum")}
+        except SystemExit:
+            pass
+        doc[wl] = {"fixture": fixture, "kernels": kernels, "tiles_per_frame": tiles, "traffic_per_frame": traffic}
     with open(f"profiles/{tag}_raster.json", "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(doc))
