@@ -402,13 +402,27 @@ SRT_DEV void object_queueN(const DScene& S, uint32_t k, V3 org, const V3* d, con
       od[r] = v3(q[r][0], q[r][1], q[r][2]);
     }
   }
+  // The first step of the walk is taken here: BVH<Triangle>::find_closest_hit tests the root's two child boxes with the object-space
+  // ray and returns "no hit" when both miss (student/bvh.inl:182-186).  The ray-cast kernel would find exactly that - same record,
+  // same BBox::hit arithmetic (box_hit_rec), same reciprocal direction - after fetching the request, setting the walk up and
+  // retiring it; a ray that misses both boxes gets its answer written straight into the hit plane and is never queued.  (A ray
+  // is asked about the mesh whenever it hits either box of the TLAS node ABOVE the mesh's leaf; most of those pass the mesh by.)
+  const WaveInterior& root = S.blas_recs[o.rec_base];
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     if (need[r]) {
       const size_t pos = (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP.nlanes + lane_global;
-      nt_store_ray(QP.ray_o, pos, oorg.x, oorg.y, oorg.z, ob0[r]);
-      nt_store_ray(QP.ray_d, pos, od[r].x, od[r].y, od[r].z, ob1[r]);
-      emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
+      const V3 cinv = v3(1.0f / od[r].x, 1.0f / od[r].y, 1.0f / od[r].z);
+      float ta = 0.0f, tb = 0.0f, tc = 0.0f, td = 0.0f;
+      const bool hl = box_hit_rec(root.boxl, oorg, cinv, ta, tb);
+      const bool hr = box_hit_rec(root.boxr, oorg, cinv, tc, td);
+      if (hl || hr) {
+        nt_store_ray(QP.ray_o, pos, oorg.x, oorg.y, oorg.z, ob0[r]);
+        nt_store_ray(QP.ray_d, pos, od[r].x, od[r].y, od[r].z, ob1[r]);
+        emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
+      } else {
+        __builtin_nontemporal_store(u32x2_t{0u, 0xFFFFFFFFu}, reinterpret_cast<u32x2_t*>(const_cast<uint2*>(QP.hits)) + pos);
+      }
     }
   }
 }
