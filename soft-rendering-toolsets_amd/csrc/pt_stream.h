@@ -66,10 +66,13 @@ struct LdsStack {
   uint32_t gstride;
   // The LDS access is unconditional (clamped index) and the global one sits behind a wave-uniform test: with both behind
   // per-lane branches the compiler merges them into FLAT loads of a selected address, which wait on both counters.
+  // (frame index x 192 dwords with the 24-bit multiply: a full 32-bit integer multiply issues at a quarter of the rate, and this one
+  //  sits in every push and every pop)
   SRT_DEV void load3(int i, uint32_t& w0, uint32_t& w1, uint32_t& w2) const {
     const bool deep = i >= k;
     const int il = deep ? 0 : i;
-    w0 = w[(il * 3 + 0) * 64]; w1 = w[(il * 3 + 1) * 64]; w2 = w[(il * 3 + 2) * 64];
+    const lds_u32* f = w + __umul24((uint32_t)il, 192u);
+    w0 = f[0]; w1 = f[64]; w2 = f[128];
     if (__ballot(deep) != 0ull) {
       if (deep) {
         const size_t at = (size_t)(i - k) * 3u * gstride;
@@ -79,7 +82,7 @@ struct LdsStack {
   }
   SRT_DEV void store3(int i, uint32_t w0, uint32_t w1, uint32_t w2) const {
     const bool deep = i >= k;
-    if (!deep) { w[(i * 3 + 0) * 64] = w0; w[(i * 3 + 1) * 64] = w1; w[(i * 3 + 2) * 64] = w2; }
+    if (!deep) { lds_u32* f = w + __umul24((uint32_t)i, 192u); f[0] = w0; f[64] = w1; f[128] = w2; }
     if (__ballot(deep) != 0ull) {
       if (deep) {
         const size_t at = (size_t)(i - k) * 3u * gstride;
@@ -433,8 +436,10 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
         F.ret = flat_no_hit();
         if (n != 0u && n <= 4u) {
           Tri g[4];
+          // (48-byte records: the byte offset by shift-and-add - first * 48 < 2^32 for < 2^26 triangles - instead of a 64-bit multiply-add)
+          const char* tb = reinterpret_cast<const char*>(S.tris) + ((((first << 1) + first)) << 4);
 #pragma unroll
-          for (uint32_t i = 0; i < 4u; i++) g[i] = S.tris[first + (i < n ? i : n - 1u)];
+          for (uint32_t i = 0; i < 4u; i++) g[i] = *reinterpret_cast<const Tri*>(tb + (i < n ? i : n - 1u) * 48u);
           TriHit th[4];
           tri_hit_leaf4(g, ray, th);
 #pragma unroll

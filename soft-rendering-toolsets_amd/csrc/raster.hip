@@ -86,7 +86,9 @@ struct LineAux {
   int32_t k0, kmax;               // steps with a table entry (kmax < k0: none)
   uint32_t tab;                   // offset of step k0's entry in the table
   uint32_t steep;
-  uint32_t pad[3];
+  uint32_t flat;                  // gradient == 0 (an axis-aligned line - the canvas outline, rectangles): intery never changes, x + 0 = x,
+  float flat_y;                   // so the chain and the table are skipped and every step's value is this one
+  uint32_t pad;
 };
 static_assert(sizeof(LineAux) == 64, "LineAux is read with scalar loads, 64 bytes");
 
@@ -135,7 +137,7 @@ __device__ int4 setup_line(const RasterParams& P, const srt_prim& p, LineAux* __
   const float dx = x1 - x0, dy = y1 - y0;
   const float gradient = (dx == 0.0f) ? 1.0f : dy / dx;
   LineAux A;
-  A.steep = steep ? 1u : 0u; A.pad[0] = A.pad[1] = A.pad[2] = 0u;
+  A.steep = steep ? 1u : 0u; A.flat = 0u; A.flat_y = 0.0f; A.pad = 0u;
   // first end point
   float xend = roundf(x0);
   float yend = y0 + gradient * (xend - x0);
@@ -164,6 +166,12 @@ __device__ int4 setup_line(const RasterParams& P, const srt_prim& p, LineAux* __
       if (ka <= kb) {
         A.first = (int32_t)first; A.k0 = (int32_t)ka; A.kmax = (int32_t)kb;
         const uint32_t n = (uint32_t)(A.kmax - A.k0) + 1u;
+        if (gradient == 0.0f) {
+          // intery + 0 == intery at every step (a -0 start becomes +0 after the first addition: the same pixel, the same fractional
+          // part +0): no chain to run, no table to fill - the four 1000-step outline lines of BASELINE configs[1] were 8 of setup's 14 us
+          A.flat = 1u; A.flat_y = intery;
+          mlo = fminf(mlo, wu_ipart(intery)); mhi = fmaxf(mhi, wu_ipart(intery) + 1);
+        } else {
         A.tab = atomicAdd(&status[FS_TABLE_NEED], n);
         const bool fits = (uint64_t)A.tab + n <= (uint64_t)table_cap;
         // the reference's serial chain, step by step: first the steps left of / above the target (nothing to keep), then the
@@ -189,6 +197,7 @@ __device__ int4 setup_line(const RasterParams& P, const srt_prim& p, LineAux* __
         // (x + g is monotone in the number of steps: the chain's extremes are its ends)
         mlo = fminf(mlo, wu_ipart(fminf(ilo, ihi))); mhi = fmaxf(mhi, wu_ipart(fmaxf(ilo, ihi)) + 1);
         if (!fits) A.kmax = A.k0 - 1;
+        }
       }
     }
   }
@@ -236,6 +245,12 @@ __global__ void raster_setup(RasterParams P, const srt_prim* __restrict__ prims,
     if (ok && stats) {
       const double nx = hix - lox + 1.0, ny = hiy - loy + 1.0;
       if (nx * ny < 1.8e19) atomicAdd(&stats[ST_TESTS_REF], (unsigned long long)(nx * ny));
+      // ... and the part of them inside the sample grid (what the tile kernel evaluates, or proves empty without evaluating)
+      const double wx = (double)(P.ssw - 1), wy = (double)(P.ssh - 1);
+      if (hix >= 0.0 && lox <= wx && hiy >= 0.0 && loy <= wy) {
+        const double cx = (hix > wx ? wx : hix) - (lox < 0.0 ? 0.0 : lox) + 1.0, cy = (hiy > wy ? wy : hiy) - (loy < 0.0 ? 0.0 : loy) + 1.0;
+        atomicAdd(&stats[ST_TESTS_TARGET], (unsigned long long)(cx * cy));
+      }
     }
   } else if (p.kind == SRT_PRIM_POINT) {
     // fill_sample((int)(x*sr + i), (int)(y*sr + j)) for i,j in [0,sr)   (cpp:296-300)
@@ -278,6 +293,39 @@ __device__ __forceinline__ uint32_t bins_of_super(const RasterParams& P, uint32_
   return bw * bh;
 }
 
+// Does a triangle cover NO sample of the rectangle [x0, x1] x [y0, y1] (sample indices, inside the target)?  Each edge function, as
+// the reference rounds it - c = (float)(fl64(e.x * fl64(p.y - v.y)) - fl64(e.y * fl64(p.x - v.x))) with p = index / sample_rate in
+// fp64 - is monotone in the sample's column and in its row (every rounding is a non-decreasing map), so over the rectangle it lies
+// between its values at the four corners.  If every edge keeps one strict sign there, well away from zero (inside_triangle's
+// sign products c_i * c_j then cannot underflow to a zero that passes both its tests), and the three signs are not all equal, no
+// sample of the rectangle is covered.  Conservative: anything doubtful (an edge that changes sign or comes near zero, NaN)
+// answers false.  Same expressions, same order as the tile kernel's row loop.
+__device__ __forceinline__ bool triangle_misses_rect(const srt_prim& p, double sr, int x0, int y0, int x1, int y1) {
+  const double ax = (double)p.v.tri[0], ay = (double)p.v.tri[1], bx = (double)p.v.tri[2], by = (double)p.v.tri[3];
+  const double cx = (double)p.v.tri[4], cy = (double)p.v.tri[5];
+  const double ex[3] = {bx - ax, cx - bx, ax - cx}, ey[3] = {by - ay, cy - by, ay - cy};
+  const double vx[3] = {ax, bx, cx}, vy[3] = {ay, by, cy};
+  const double px[2] = {(double)x0 / sr, (double)x1 / sr}, py[2] = {(double)y0 / sr, (double)y1 / sr};
+  bool all_pos = true, all_neg = true;
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    bool pos = true, neg = true;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const double k = ey[e] * (px[i] - vx[e]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const float c = (float)(ex[e] * (py[j] - vy[e]) - k);
+        pos = pos && c > 1e-18f;
+        neg = neg && c < -1e-18f;
+      }
+    }
+    if (!pos && !neg) return false;
+    all_pos = all_pos && pos; all_neg = all_neg && neg;
+  }
+  return !all_pos && !all_neg;
+}
+
 #ifndef SRT_BIN_K1
 #define SRT_BIN_K1 24
 #endif
@@ -288,7 +336,7 @@ template <int LEVEL>
 __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const int4* __restrict__ bbox, const uint32_t* __restrict__ in_lists,
                                                          const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_lists,
                                                          uint32_t* __restrict__ out_counts, uint32_t* __restrict__ offs,
-                                                         uint32_t list_cap, uint32_t* __restrict__ status) {
+                                                         uint32_t list_cap, uint32_t* __restrict__ status, const srt_prim* __restrict__ prims) {
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_fits;
   bool fits = true;
@@ -348,8 +396,15 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
     for (int j = 0; j < K; j++) {
       const uint32_t k = base + (uint32_t)j * blockDim.x + threadIdx.x;
       int4 bb = make_int4(1, 1, 0, 0);
-      if (k < ncand) bb = bbox[(LEVEL == 1) ? k : in[k]];
-      const bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+      uint32_t pi = 0;
+      if (k < ncand) { pi = (LEVEL == 1) ? k : in[k]; bb = bbox[pi]; }
+      bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+      if (LEVEL == 2 && ov) {
+        // a triangle whose box reaches into this bin but which covers none of the bin's samples is not listed: a sliver's box is
+        // most of the target, its samples a thin band (the stress frame: 11.7 M (primitive, tile) pairs listed by boxes alone)
+        const srt_prim p = prims[pi];
+        if (p.kind == SRT_PRIM_TRIANGLE && triangle_misses_rect(p, (double)P.sr, max(bb.x, x0), max(bb.y, y0), min(bb.z, x1), min(bb.w, y1))) ov = false;
+      }
       const unsigned long long m = __ballot(ov);
       if (lane == 0) s_mask[j * 16 + wave] = (wave < nwaves) ? m : 0ull;
       mine |= (ov ? 1u : 0u) << j;
@@ -455,7 +510,14 @@ template <bool STATS, int TSY, bool IMG>
 #ifndef SRT_RASTER_OCC
 #define SRT_RASTER_OCC 5
 #endif
-__global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
+#ifndef SRT_RASTER_OCC_NOIMG
+#define SRT_RASTER_OCC_NOIMG 6
+#endif
+// (the image-free build needs 79 VGPRs: six waves per SIMD without a spill - 24 waves per CU with 8-high tiles, whose 4 KiB of LDS
+//  per wave leave room; 16-high tiles stay LDS-limited at 19.  Measured: five to eight waves per SIMD all give 0.164-0.168 ms per
+//  cfg2 frame - the kernel is not short of waves.  Two tiles per wave in a loop: cfg2 0.143 -> 0.135 ms, the stress frame 6.65 -> 7.0 ms,
+//  and the loop itself cost the one-tile case 7 %: not kept.)
+__global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RASTER_OCC : SRT_RASTER_OCC_NOIMG)) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
                                                      const uint32_t* __restrict__ counts,
@@ -483,14 +545,15 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
   const int tsh = min((int)P.tile_sy, (int)P.ssh - sy0);
   const int sx1 = sx0 + tsw - 1, sy1 = sy0 + tsh - 1;
 
-  // clear_target: every sample starts at 255.0f (software_renderer.h:93-98)
+  // clear_target: every sample starts at 255.0f (software_renderer.h:93-98) - done when the first primitive reaches the tile
+  // (`touched`, below).  A tile no primitive reaches - 40 % of BASELINE configs[1]'s tiles - never clears its LDS, computes no
+  // coordinates and runs no box filter: sr^2 samples of 255.0f sum and divide back to exactly 255.0f, the pixel is 0xFFFFFFFF.
   const float4 white = make_float4(255.0f, 255.0f, 255.0f, 255.0f);
-  for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
-  if (lane < TSY) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
+  bool touched = false;
 
   const int lx = lane & (TS - 1);
   const int lrow = lane >> 5;
-  const double px = (double)(sx0 + lx) / (double)P.sr;  // x / sample_rate (cpp:510)
+  double px = 0.0;  // x / sample_rate (cpp:510), set with the clear
   // Pixel of a sample (lines compare pixels): the tile's origin is a whole pixel (tx * tile_px, ty * tile_py) and the offset inside
   // the tile is below 32, so floor(o / sr) = (int)((o + 0.5) * (1 / sr)) exactly - (o + 0.5) / sr is at least 1 / 64 away from
   // every integer, far more than the rounding of the reciprocal and the product - and no integer division is spent on it.
@@ -498,9 +561,8 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
   const int tpx0 = tx * (int)P.tile_px, tpy0 = ty * (int)P.tile_py;           // pixel rectangle of the tile (uniform)
   const int tpx1 = tpx0 + (int)(((float)(tsw - 1) + 0.5f) * rsr), tpy1 = tpy0 + (int)(((float)(tsh - 1) + 0.5f) * rsr);
   const int colpix = tpx0 + (int)(((float)lx + 0.5f) * rsr);
-  __syncthreads();
 
-  unsigned long long n_tests = 0, n_frags = 0, n_pts = 0, n_bins = 0;
+  unsigned long long n_frags = 0, n_pts = 0, n_bins = 0;
 
   // this tile's coarse bin: an ordered list of primitive indices
   const uint32_t bin = (uint32_t)(ty / (int)P.coarse_tiles) * P.coarse_x + (uint32_t)(tx / (int)P.coarse_tiles);
@@ -517,6 +579,13 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
     if (base + WAVE + lane < n) { nidx = list[base + WAVE + lane]; nbb = bbox[nidx]; }
     const bool overlaps = (base + lane < n) && (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
     unsigned long long mask = __ballot(overlaps);
+    if (mask != 0ull && !touched) {                      // (uniform) the first primitive of this tile: clear_target + the tile's coordinates
+      for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
+      if (lane < TSY) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
+      px = (double)(sx0 + lx) / (double)P.sr;
+      touched = true;
+      __syncthreads();
+    }
     // every overlapping lane fetches ITS primitive record now (three 16-byte loads in flight per lane); the ordered
     // loop below then reads records lane by lane with v_readlane instead of paying one memory round trip per primitive
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0;
@@ -555,9 +624,30 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
         // e.y * (p.x - v.x) does not depend on the row: one fp64 product per edge per primitive instead of per sample
         const double k0 = e0y * d0x, k1 = e1y * d1x, k2 = e2y * d2x;
         const bool xin = (lx >= rx0) && (lx <= rx1);
-        if (STATS) n_tests += (unsigned long long)(rx1 - rx0 + 1) * (unsigned long long)(ry1 - ry0 + 1);
 
-        for (int row = ry0 + lrow; row <= ry1; row += 2) {
+        // Does the triangle miss the whole rectangle?  Each edge function, as the reference rounds it - (float)(fl64(e.x * fl64(p.y - v.y))
+        // - fl64(e.y * fl64(p.x - v.x))) - is monotone in the sample's column and in its row (every rounding is a non-decreasing map),
+        // so over the rectangle it lies between its values at the four corners.  If every edge keeps one strict sign there, well away
+        // from zero (the sign products of inside_triangle then cannot underflow to a zero that passes both tests), and the three signs
+        // are not all equal, no sample of the rectangle is covered and the row loop is skipped.  Worth its ~90 instructions when the
+        // rectangle has six rows or more: the stress frame's slivers each box most of the target and cover 0.2 % of what they test.
+        bool misses = false;
+        if (ry1 - ry0 >= 5) {
+          const double pya = rowy[ry0], pyb = rowy[ry1];
+          const float ca[3] = {(float)(e0x * (pya - ay) - k0), (float)(e1x * (pya - by) - k1), (float)(e2x * (pya - cy) - k2)};
+          const float cz[3] = {(float)(e0x * (pyb - ay) - k0), (float)(e1x * (pyb - by) - k1), (float)(e2x * (pyb - cy) - k2)};
+          bool pos[3], neg[3];
+#pragma unroll
+          for (int e = 0; e < 3; e++) {          // lanes rx0 and rx1 (row parity 0) hold the rectangle's first and last column
+            const float v0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ca[e]), rx0)), v1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ca[e]), rx1));
+            const float v2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cz[e]), rx0)), v3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cz[e]), rx1));
+            pos[e] = v0 > 1e-18f && v1 > 1e-18f && v2 > 1e-18f && v3 > 1e-18f;      // (false for NaN)
+            neg[e] = v0 < -1e-18f && v1 < -1e-18f && v2 < -1e-18f && v3 < -1e-18f;
+          }
+          misses = (pos[0] || neg[0]) && (pos[1] || neg[1]) && (pos[2] || neg[2]) && !(pos[0] && pos[1] && pos[2]) && !(neg[0] && neg[1] && neg[2]);
+        }
+
+        for (int row = misses ? ry1 + 1 : ry0 + lrow; row <= ry1; row += 2) {
           const double py = rowy[row];
           const double d0y = py - ay, d1y = py - by, d2y = py - cy;
           const float c1 = (float)(e0x * d0y - k0);
@@ -592,7 +682,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
           // they fill lie between the two ends' values
           const int ka = max(tM0 - A.first, A.k0), kb = min(tM1 - A.first, A.kmax);
           if (ka <= kb) {
-            const float ya = ltable[A.tab + (uint32_t)(ka - A.k0)], yb = ltable[A.tab + (uint32_t)(kb - A.k0)];
+            const float ya = A.flat ? A.flat_y : ltable[A.tab + (uint32_t)(ka - A.k0)], yb = A.flat ? A.flat_y : ltable[A.tab + (uint32_t)(kb - A.k0)];
             const float ylo = floorf(fminf(ya, yb)), yhi = floorf(fmaxf(ya, yb)) + 1;
             st_main = !(yhi < (float)tm0) && !(ylo > (float)tm1);          // (NaN: stays in, fills nothing)
           }
@@ -616,8 +706,8 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
             if (st_main) {
               const int k = Mi - A.first;
               const bool in_k = xin && k >= A.k0 && k <= A.kmax;
-              float iy = 0.0f;
-              if (in_k) iy = ltable[A.tab + (uint32_t)(k - A.k0)];
+              float iy = A.flat_y;
+              if (in_k && !A.flat) iy = ltable[A.tab + (uint32_t)(k - A.k0)];
               const float ip = floorf(iy), fp = iy - ip;                      // ipart, fpart
               const bool ht = in_k && m == ip, hb = in_k && m == ip + 1;      // rasterize_point(x, ipart), (x, ipart + 1)
               if (ht || hb) tile[si] = blend_over(tile[si], cr, cg, cb, ht ? 1 - (1 - fp) : 1 - fp);   // 1 - rfpart / 1 - fpart
@@ -696,6 +786,13 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
   const int pw = tsw / sr, ph = tsh / sr;
   const int px0 = tx * (int)P.tile_px, py0 = ty * (int)P.tile_py;
   const float denom = (float)((size_t)P.sr * (size_t)P.sr);
+  if (!touched) {                                        // an untouched tile: every pixel (255, 255, 255, 255), every sample 255.0f
+    for (int k = lane; k < pw * ph; k += WAVE) rgba_out[(size_t)(py0 + k / pw) * P.w + (px0 + k % pw)] = 0xFFFFFFFFu;
+    if (samples_out)
+      for (int k = lane; k < tsw * tsh; k += WAVE) samples_out[(size_t)(sy0 + k / tsw) * P.ssw + (sx0 + k % tsw)] = white;
+    if (STATS && lane == 0) atomicAdd(&stats[ST_BIN_ENTRIES], n_bins);
+    return;
+  }
   for (int k = lane; k < pw * ph; k += WAVE) {
     const int pxl = k % pw, pyl = k / pw;
     float r = 0, g = 0, bl = 0, a = 0;
@@ -720,7 +817,6 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : SRT_RASTER_OCC) void raster_t
 
   if (STATS) {
     if (lane == 0) {
-      atomicAdd(&stats[ST_TESTS_TARGET], n_tests);
       atomicAdd(&stats[ST_FRAGMENTS], n_frags);
       atomicAdd(&stats[ST_POINT_SAMPLES], n_pts);
       atomicAdd(&stats[ST_BIN_ENTRIES], n_bins);
@@ -1016,9 +1112,9 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
     }
     // Ordered binning (raster_bin_pass): coarse bins of c x c tiles under <= 8 x 8 super-bins
     uint32_t* d_super_counts = r->d_super + ns * P.super_stride;
-    raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr, 0u, r->d_status);
+    raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr, 0u, r->d_status, r->d_prims);
     raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, r->d_lists, r->d_counts, r->d_counts + nb,
-                                                                (uint32_t)std::min<size_t>(r->lists_cap, 0xFFFFFFFFull), r->d_status);
+                                                                (uint32_t)std::min<size_t>(r->lists_cap, 0xFFFFFFFFull), r->d_status, r->d_prims);
     r->bins_valid = true;
   }
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
