@@ -229,6 +229,11 @@ def raster_bench(device, frames=30, warmup=3):
                             "(SVG walk + triangulation on the host, upload, setup, binning, tiles, resolve, 4 MiB read-back into the "
                             "application's framebuffer), draw_svg_redraw_wall_ms = unchanged view (tile kernel + read-back)"}
             ok = ok and wall["framebuffer_equals_reference_golden"]
+            ph = (ctypes.c_double * 5)()
+            if hasattr(lib, "dropin_raster_phases") and lib.dropin_raster_phases(svg.encode(), device, w, h, sr, frames, ph) == 0:
+                # the same redraw step by step over the C ABI: where the wall time goes (host clock around each step)
+                wall["phases_ms"] = {"application_clear_target_memset": ph[0], "host_stream_build": ph[1], "clear_and_submit": ph[2],
+                                     "resolve_upload_kernels_readback_wait": ph[3], "redraw": ph[4]}
     e2e_ms = wall["draw_svg_wall_ms"] if wall else abi_new_ms
     # what binds the tile kernel: vector-instruction issue and LDS, from the committed SQ counter passes of the same kernel sources
     prof, why_not = None, "no committed PMC pass for the rasterizer"

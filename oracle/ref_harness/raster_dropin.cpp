@@ -141,4 +141,45 @@ int dropin_raster_bench(const char* path, int device, uint32_t w, uint32_t h, ui
   return 0;
 }
 
+// Where a redraw's wall time goes: the steps of DrawSVG::redraw + SoftwareRendererHIP::draw_svg taken one by one over the C ABI
+// (same calls, same order, a moving view), each timed on the host.  ms_out[0..4]: the application's clear_target (the 4 x w x h
+// memset of the base class, drawsvg.cpp:274-281), SvgStreamBuilder::build, srt_raster_clear + clear_textures + submit,
+// srt_raster_resolve (upload, kernels, read-back, one wait), and the whole redraw.
+int dropin_raster_phases(const char* path, int device, uint32_t w, uint32_t h, uint32_t sample_rate, uint32_t frames, double ms_out[5]) {
+  SVG* svg = new SVG();
+  if (SVGParser::load(path, svg) < 0) return -1;
+  srt_raster* ctx = nullptr;
+  if (srt_raster_create(device, &ctx) != SRT_OK) return -2;
+  ViewportImp* viewport = new ViewportImp();
+  const float sw = svg->width, sh = svg->height;
+  const float span = 1.2 * std::max(sw, sh) / 2;
+  std::vector<unsigned char> framebuffer(4 * (size_t)w * h);
+  if (srt_raster_set_target(ctx, w, h, sample_rate) != SRT_OK || srt_raster_bind_output(ctx, framebuffer.data(), framebuffer.size()) != SRT_OK) return -3;
+  Matrix3x3 norm_to_screen = Matrix3x3::identity();
+  float scale = std::min(w, h);
+  norm_to_screen(0, 0) = scale; norm_to_screen(0, 2) = (w - scale) / 2;
+  norm_to_screen(1, 1) = scale; norm_to_screen(1, 2) = (h - scale) / 2;
+  SvgStreamBuilder builder;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int i = 0; i < 5; i++) ms_out[i] = 0.0;
+  for (uint32_t k = 0; k < frames + 3; k++) {
+    viewport->set_viewbox(sw / 2 + 0.37f * (float)(k % 5), sh / 2 - 0.21f * (float)(k % 3), span);
+    const double t0 = now();
+    std::memset(framebuffer.data(), 255, framebuffer.size());
+    const double t1 = now();
+    Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
+    const std::vector<srt_prim>& stream = builder.build(*svg, m_imp, sample_rate);
+    const double t2 = now();
+    if (srt_raster_clear(ctx) != SRT_OK || srt_raster_clear_textures(ctx) != SRT_OK || srt_raster_submit(ctx, stream.data(), stream.size()) != SRT_OK) return -4;
+    const double t3 = now();
+    if (srt_raster_resolve(ctx, framebuffer.data()) != SRT_OK) return -5;
+    const double t4 = now();
+    if (k >= 3) { ms_out[0] += t1 - t0; ms_out[1] += t2 - t1; ms_out[2] += t3 - t2; ms_out[3] += t4 - t3; ms_out[4] += t4 - t0; }
+  }
+  for (int i = 0; i < 5; i++) ms_out[i] /= frames;
+  srt_raster_bind_output(ctx, nullptr, 0);
+  srt_raster_destroy(ctx);
+  return 0;
+}
+
 }  // extern "C"

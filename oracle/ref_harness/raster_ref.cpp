@@ -107,6 +107,28 @@ long ref_raster_svg_stream(const char* path, uint32_t w, uint32_t h, uint32_t sr
   return (long)s.size();
 }
 
+// The host walk's own shortcuts (points transformed inline and once per polygon point, svg_stream.cpp) against the same walk
+// with every corner sent through the reference's SVGRenderer::transform: 0 if the two streams are byte-identical, else
+// 1 + the index of the first record that differs (or 1 + the shorter length).  Two views: the initial framing and a skewed,
+// shifted one (`variant` 1) so that the matrix entries are not round numbers.
+long ref_raster_svg_stream_ab(const char* path, uint32_t w, uint32_t h, uint32_t sr, uint32_t variant) {
+  SVG* svg = new SVG();
+  if (SVGParser::load(path, svg) < 0) return -1;
+  Matrix3x3 m = initial_svg_2_screen(*svg, w, h);
+  if (variant) { m(0, 0) *= 1.0 / 3.0; m(0, 1) += 0.1234567; m(1, 0) -= 0.0714285; m(0, 2) += 17.3; m(1, 2) -= 5.7; m(2, 0) += 1e-4; m(2, 2) = 0.93; }
+  SvgStreamBuilder fast, slow;
+  slow.set_reference_transforms(true);
+  for (int pass = 0; pass < 2; pass++) {   // (the second pass runs on warm triangulation caches)
+    const std::vector<srt_prim>& a = fast.build(*svg, m, sr);
+    const std::vector<srt_prim>& b = slow.build(*svg, m, sr);
+    const size_t n = a.size() < b.size() ? a.size() : b.size();
+    for (size_t i = 0; i < n; i++)
+      if (std::memcmp(&a[i], &b[i], sizeof(srt_prim)) != 0) return (long)i + 1;
+    if (a.size() != b.size()) return (long)n + 1;
+  }
+  return 0;
+}
+
 // The textures the stream of the same SVG refers to (SvgStreamBuilder::textures() order), with the mip chains the
 // reference's Sampler2DImp::generate_mips builds.  tex_nlevels[<= max_tex]; level_w / level_h / level_off per level,
 // concatenated over the textures; blob receives the texels.  Returns the number of textures, <0 on error / overflow.

@@ -16,7 +16,11 @@ namespace CMU462 {
 
 class SvgStreamBuilder : public SVGRenderer {
  public:
-  SvgStreamBuilder() : sample_rate_(1) {}
+  SvgStreamBuilder() : sample_rate_(1), reference_transforms_(false), last_size_(0) {}
+
+  // true: every point goes through SVGRenderer::transform itself, corner by corner, as in the reference's draw_* functions
+  // (the checker's setting; the default computes the same doubles inline and once per polygon point - see svg_stream.cpp)
+  void set_reference_transforms(bool on) { reference_transforms_ = on; }
 
   // SVGRenderer interface: same as build().
   void draw_svg(SVG& svg) { build(svg, transformation, sample_rate_); }
@@ -39,9 +43,15 @@ class SvgStreamBuilder : public SVGRenderer {
   void emit_image(float x0, float y0, float x1, float y1, const Texture& tex);
 
   // triangulate() results per polygon element, valid while the polygon's points are what they were (see walk())
-  struct CachedTriangulation { bool valid; std::vector<Vector2D> points, tris; CachedTriangulation() : valid(false) {} };
-  const std::vector<Vector2D>& triangulation_of(const Polygon& pg);
+  // (index: per corner of tris, which of the polygon's points it is; empty if some corner is none of them)
+  struct CachedTriangulation { bool valid; std::vector<Vector2D> points, tris; std::vector<uint32_t> index; CachedTriangulation() : valid(false) {} };
+  const CachedTriangulation& triangulation_of(const Polygon& pg);
   std::map<const Polygon*, CachedTriangulation> tri_cache_;
+  struct PointMap;
+  const std::vector<Vector2D>& transformed(const std::vector<Vector2D>& points);
+  std::vector<Vector2D> scratch_;
+  bool reference_transforms_;
+  size_t last_size_;
 
   size_t sample_rate_;
   std::vector<srt_prim> stream_;

@@ -1,5 +1,6 @@
 """CPU: pin oracle/raster_oracle.c against the golden vectors produced by the reference's own code
 (tests/golden/make_raster_golden.py) and, in the authoring container, against the reference build."""
+import ctypes
 import glob
 import os
 
@@ -90,3 +91,26 @@ def test_oracle_matches_reference_build_random(sr):
         o_rgba, o_ss, _ = H.oracle_raster_frame(prims, w, h, sr, want_samples=True)
         assert np.array_equal(r_rgba, o_rgba)
         assert np.array_equal(r_ss.view(np.uint32), o_ss.view(np.uint32))
+
+
+def _svg_files():
+    """Every SVG of the reference when its tree is here, else the three committed under tests/golden/svg."""
+    import glob
+    ref = sorted(glob.glob("/root/reference/Assignments/DrawSVG/svg/*/*.svg"))
+    return ref or sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "svg", "*.svg")))
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(H.ref_raster() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_host_walk_shortcuts_keep_the_stream_byte_identical():
+    """host/svg_stream.cpp transforms a polygon's points inline and once per point; with set_reference_transforms(true) every
+    corner goes through the reference's SVGRenderer::transform instead.  The two streams must not differ in one byte, in the
+    initial framing and under a skewed projective matrix, cold and on warm triangulation caches."""
+    lib = H.ref_raster()
+    lib.ref_raster_svg_stream_ab.restype = ctypes.c_long
+    files = _svg_files()
+    assert files
+    for path in files:
+        for variant in (0, 1):
+            for (w, h, sr) in ((256, 256, 1), (1024, 768, 4)):
+                assert lib.ref_raster_svg_stream_ab(path.encode(), w, h, sr, variant) == 0, (path, variant, w, h, sr)
