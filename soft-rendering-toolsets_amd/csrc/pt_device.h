@@ -551,10 +551,11 @@ SRT_DEV void tri_hitN(const Tri& g, V3 org, const V3* d, const float* b0, const 
 // Triangle::hit of the (up to) four triangles of a BVH<Triangle> leaf for ONE ray: the twelve quotients and four
 // distances go through divNx3 / sqrtN together (one range verdict, independent refinement chains).  Same arithmetic per
 // triangle as tri_hit.
-SRT_DEV void tri_hit_leaf4(const Tri* g, const Ray& ray, TriHit* h) {
-  float num[4][3], det[4], q[4][3], n2[4], nr[4];
+template <int N>
+SRT_DEV void tri_hit_leafN(const Tri* g, const Ray& ray, TriHit* h) {
+  float num[N][3], det[N], q[N][3], n2[N], nr[N];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     const V3 e1 = v3p(g[k].e1), e2 = v3p(g[k].e2);
     const V3 s = ray.o - v3p(g[k].p0);
     const V3 e1xd = cross(e1, ray.d);
@@ -564,13 +565,13 @@ SRT_DEV void tri_hit_leaf4(const Tri* g, const Ray& ray, TriHit* h) {
     num[k][1] = dot(e1xd, s);
     num[k][2] = -1.0f * dot(sxe2, e1);
   }
-  divNx3<4, false>(num, det, q);
-  bool zero[4];
+  divNx3<N, false>(num, det, q);
+  bool zero[N];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { n2[k] = norm2(ray.d * q[k][2]); zero[k] = false; }
-  sqrtN<4>(n2, zero, nr);
+  for (int k = 0; k < N; k++) { n2[k] = norm2(ray.d * q[k][2]); zero[k] = false; }
+  sqrtN<N>(n2, zero, nr);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < N; k++) {
     h[k].u = q[k][0]; h[k].v = q[k][1]; h[k].t = q[k][2];
     const bool outside = (h[k].u < 0) || (h[k].v < 0) || ((1.0f - h[k].u - h[k].v) < 0) || (h[k].t < 0);
     h[k].dist = fabsf(nr[k]);
@@ -578,6 +579,7 @@ SRT_DEV void tri_hit_leaf4(const Tri* g, const Ray& ray, TriHit* h) {
     h[k].hit = (det[k] != 0) && !outside && !out_of_bounds;
   }
 }
+SRT_DEV void tri_hit_leaf4(const Tri* g, const Ray& ray, TriHit* h) { tri_hit_leafN<4>(g, ray, h); }
 
 // Sphere::hit (student/shapes.cpp:17-80).  The reference's unqualified sqrt(delta) is the double overload,
 // so the numerator sum and the quotient are fp64 before narrowing to t1/t2.  Straight-line form as above.

@@ -59,6 +59,7 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 SRT_DEV void nt_store_ray(float4* plane, size_t i, float x, float y, float z, float w) { __builtin_nontemporal_store(f32x4{x, y, z, w}, reinterpret_cast<f32x4*>(plane) + i); }
 SRT_DEV uint2 nt_load_hit(const uint2* hits, size_t i) { const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hits) + i); return make_uint2(v.x, v.y); }
 typedef __attribute__((address_space(3))) uint32_t lds_u32;   // (an explicit LDS pointer: ds_read / ds_write, never FLAT)
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 struct LdsStack {
   lds_u32* w;    // this lane's column: word k of frame i at w[(i * 3 + k) * 64]
   uint32_t* g;
@@ -267,6 +268,12 @@ SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
 #ifndef SRT_CAST_OCC
 #define SRT_CAST_OCC 4
 #endif
+#ifndef SRT_CAST_POPS_UNROLLED
+#define SRT_CAST_POPS_UNROLLED 1
+#endif
+#ifndef SRT_CAST_LEAF_SPREAD
+#define SRT_CAST_LEAF_SPREAD 1
+#endif
 #ifndef SRT_CAST_OCC_WALK
 #define SRT_CAST_OCC_WALK 5
 #endif
@@ -274,6 +281,9 @@ SRT_DEV void cast_enter_leaf_objects(FlatState& F) {
 template <bool STATS, bool WALK>
 __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void pt_cast_kernel(DScene S, CastParams P) {
   extern __shared__ uint32_t cast_lds[];
+#if SRT_CAST_LEAF_SPREAD
+  __shared__ uint8_t cast_pairs[4 * 64];                  // leaf phase: owner lane | place in the leaf << 6 of each (ray, triangle) pair, per wave
+#endif
   const uint32_t nrays = *P.nrays;
   if (nrays == 0u) {
     // nothing to cast.  If no slot is alive either and the unit queue is drained, the launch is finished.
@@ -404,10 +414,15 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
     const bool run_obj = !WALK && !run_leaf && (n_obj >= P.object_min || n_walk == 0u);
     if (!run_leaf && !run_obj) {
       CAST_STAT(CS_INTERIOR_TRIPS, 1); CAST_STAT(CS_INTERIOR_LANES, n_walk);
+#if SRT_CAST_POPS_UNROLLED
+      if (F.mode == FM_UNWIND) cast_unwind_step<WALK>(F, stack);
+      if (F.mode == FM_UNWIND) cast_unwind_step<WALK>(F, stack);                  // (a second pop costs less than another trip)
+#else
       if (F.mode == FM_UNWIND) {
 #pragma nounroll
         for (uint32_t k = 0; k < P.pops && F.mode == FM_UNWIND; k++) cast_unwind_step<WALK>(F, stack);   // (a second pop costs less than another trip)
       }
+#endif
       // (pops first, then the interior step for every lane that stands at an interior node NOW - also the ones a pop has just
       //  sent into a farther child: they would otherwise idle through this trip's interior code and come back for the next)
       if (!WALK) cast_enter_leaf_objects(F);
@@ -428,6 +443,74 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
         cs[CS_LEAF_TRIPS]++; cs[CS_LEAF_LANES] += n_leaf; cs[CS_LEAF_TRIS] += __shfl(t, 0);
       }
+#if SRT_CAST_LEAF_SPREAD
+      {
+        // BVH<Triangle> leaves, ONE (ray, triangle) test per lane.  A lane at a leaf holds 1..4 triangles, and only ~13 lanes of
+        // the 64 stand at a leaf when the phase runs: tested by their own lanes those were four tests at a fifth of the wave.
+        // Here the pairs are dealt out over the whole wave - lane w takes pair w: the ray of its owner (nine ds_bpermute) and
+        // one triangle - and every owner then folds its own pairs' verdicts in the leaf's order (Trace::min is taken pair by
+        // pair either way: same tests, same operands, same order of folding).  At most 64 pairs per phase: the lanes whose pairs
+        // do not fit stay at their leaf for the next trip.  (A leaf of 0 or more than 4 triangles - not built by
+        // BVH::build with max_leaf_size 4, but legal - is folded by its own lane as before.)
+        const uint32_t packed = (uint32_t)~F.cur;
+        const uint32_t n = at_leaf ? (packed & 7u) : 0u;
+        const bool small = at_leaf && n >= 1u && n <= 4u;
+        const uint32_t nn = small ? n : 0u;
+        const unsigned long long b0 = __ballot((nn & 1u) != 0u), b1 = __ballot((nn & 2u) != 0u), b2 = __ballot((nn & 4u) != 0u);
+        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                             2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+                             4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+        const bool sel = small && off + nn <= 64u;             // (a prefix of the leaf lanes: `off` counts every earlier one)
+        const unsigned long long selm = __ballot(sel);
+        if (selm != 0ull) {
+          const int last = 63 - __builtin_clzll(selm);
+          const uint32_t npairs = (uint32_t)__shfl((int)(off + nn), last);
+          // who owns pair w: the owners write their lane (and the pair's place in the leaf) into the wave's 64 bytes of LDS
+          lds_u8* own = (lds_u8*)cast_pairs + wave * 64;
+          if (sel) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+              if (k < nn) own[off + k] = (uint8_t)((uint32_t)lane | (k << 6));
+          }
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t ob = own[lane];
+          __builtin_amdgcn_wave_barrier();
+          const int owner = (int)(ob & 63u);
+          const uint32_t first = F.tri_base + (packed >> 3);
+          Ray ray;
+          ray.o = v3(__shfl(F.co.x, owner), __shfl(F.co.y, owner), __shfl(F.co.z, owner));
+          ray.d = v3(__shfl(F.cd.x, owner), __shfl(F.cd.y, owner), __shfl(F.cd.z, owner));
+          ray.b0 = __shfl(F.b0, owner); ray.b1 = __shfl(F.b1, owner);
+          const uint32_t tri = (uint32_t)__shfl((int)first, owner) + (ob >> 6);
+          TriHit th; th.hit = false; th.dist = 0.0f;
+          if ((uint32_t)lane < npairs) {
+            const char* tb = reinterpret_cast<const char*>(S.tris) + (((tri << 1) + tri) << 4);   // (48-byte records, tri * 48 < 2^32)
+            const Tri g = *reinterpret_cast<const Tri*>(tb);
+            tri_hit_leafN<1>(&g, ray, &th);
+          }
+          const int hit_i = th.hit ? 1 : 0;
+          Hit acc = flat_no_hit();
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; k++) {
+            const int src = (int)((off + k) & 63u);
+            const int hk = __shfl(hit_i, src);
+            const float dk = __shfl(th.dist, src);
+            if (k < nn) fold(acc, hk != 0, dk, 0, first + k);
+          }
+          if (sel) { F.ret = acc; F.mode = FM_UNWIND; }
+        }
+        if (at_leaf && !small) {
+          const uint32_t first = F.tri_base + (packed >> 3);
+          Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
+          F.ret = flat_no_hit();
+          for (uint32_t i = 0; i < n; i++) {
+            const TriHit th = tri_hit(S.tris[first + i], ray);
+            fold(F.ret, th.hit, th.dist, 0, first + i);
+          }
+          F.mode = FM_UNWIND;
+        }
+      }
+#else
       if (at_leaf) {
         // BVH<Triangle> leaf: fold its triangles in order (spare slots repeat the last one: sane operands, never folded)
         const uint32_t packed = (uint32_t)~F.cur;
@@ -453,6 +536,7 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
         }
         F.mode = FM_UNWIND;
       }
+#endif
       CAST_STAT(CS_T_LEAF, __builtin_readcyclecounter() - t0);
     }
   }
