@@ -300,13 +300,12 @@ __device__ __forceinline__ uint32_t bins_of_super(const RasterParams& P, uint32_
 // sign products c_i * c_j then cannot underflow to a zero that passes both its tests), and the three signs are not all equal, no
 // sample of the rectangle is covered.  Conservative: anything doubtful (an edge that changes sign or comes near zero, NaN)
 // answers false.  Same expressions, same order as the tile kernel's row loop.
-__device__ __forceinline__ bool triangle_misses_rect(const srt_prim& p, double sr, int x0, int y0, int x1, int y1) {
-  const double ax = (double)p.v.tri[0], ay = (double)p.v.tri[1], bx = (double)p.v.tri[2], by = (double)p.v.tri[3];
-  const double cx = (double)p.v.tri[4], cy = (double)p.v.tri[5];
+__device__ __forceinline__ bool triangle_misses_corners(const float* t, const double px[2], const double py[2]) {
+  const double ax = (double)t[0], ay = (double)t[1], bx = (double)t[2], by = (double)t[3];
+  const double cx = (double)t[4], cy = (double)t[5];
   const double ex[3] = {bx - ax, cx - bx, ax - cx}, ey[3] = {by - ay, cy - by, ay - cy};
   const double vx[3] = {ax, bx, cx}, vy[3] = {ay, by, cy};
-  const double px[2] = {(double)x0 / sr, (double)x1 / sr}, py[2] = {(double)y0 / sr, (double)y1 / sr};
-  bool all_pos = true, all_neg = true;
+  bool all_pos = true, all_neg = true, decided = true;
 #pragma unroll
   for (int e = 0; e < 3; e++) {
     bool pos = true, neg = true;
@@ -320,10 +319,15 @@ __device__ __forceinline__ bool triangle_misses_rect(const srt_prim& p, double s
         neg = neg && c < -1e-18f;
       }
     }
-    if (!pos && !neg) return false;
+    decided = decided && (pos || neg);
     all_pos = all_pos && pos; all_neg = all_neg && neg;
   }
-  return !all_pos && !all_neg;
+  return decided && !all_pos && !all_neg;
+}
+// ... for the rectangle of samples [x0, x1] x [y0, y1] (sample coordinates of the target)
+__device__ __forceinline__ bool triangle_misses_rect(const srt_prim& p, double sr, int x0, int y0, int x1, int y1) {
+  const double px[2] = {(double)x0 / sr, (double)x1 / sr}, py[2] = {(double)y0 / sr, (double)y1 / sr};
+  return triangle_misses_corners(p.v.tri, px, py);
 }
 
 #ifndef SRT_BIN_K1
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
     for (int k = 0; k < FS_COUNT; k++) { host_status[k] = status[k]; status[k] = 0u; }
   }
   __shared__ double rowy[TSY];       // y / sample_rate for each tile row (fp64 division done once)
+  __shared__ double colx[TS];        // x / sample_rate for each tile column
 
   const int lane = threadIdx.x;
   const int tx = blockIdx.x % P.tiles_x;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
   // (`touched`, below).  A tile no primitive reaches - 40 % of BASELINE configs[1]'s tiles - never clears its LDS, computes no
   // coordinates and runs no box filter: sr^2 samples of 255.0f sum and divide back to exactly 255.0f, the pixel is 0xFFFFFFFF.
   const float4 white = make_float4(255.0f, 255.0f, 255.0f, 255.0f);
-  bool touched = false;
+  bool touched = false, coords = false;
 
   const int lx = lane & (TS - 1);
   const int lrow = lane >> 5;
@@ -579,11 +584,11 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
     if (base + WAVE + lane < n) { nidx = list[base + WAVE + lane]; nbb = bbox[nidx]; }
     const bool overlaps = (base + lane < n) && (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
     unsigned long long mask = __ballot(overlaps);
-    if (mask != 0ull && !touched) {                      // (uniform) the first primitive of this tile: clear_target + the tile's coordinates
-      for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
+    if (mask != 0ull && !coords) {                       // (uniform) the first candidate of this tile: the tile's sample coordinates
       if (lane < TSY) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
       px = (double)(sx0 + lx) / (double)P.sr;
-      touched = true;
+      if (lane < TS) colx[lane] = px;
+      coords = true;
       __syncthreads();
     }
     // every overlapping lane fetches ITS primitive record now (three 16-byte loads in flight per lane); the ordered
@@ -592,6 +597,22 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
     if (overlaps) {
       const uint4* __restrict__ pp = reinterpret_cast<const uint4*>(prims + myidx);
       q0 = pp[0]; q1 = pp[1]; q2 = pp[2];
+    }
+    // Triangles that cover no sample of their rectangle inside this tile leave the step here, all 64 candidates at once - every
+    // lane tests ITS triangle at the rectangle's four corners (triangle_misses_corners: the reference's own edge functions, in the
+    // row loop's expressions, on the row loop's coordinates) - instead of one by one in the ordered loop: 63 % of BASELINE
+    // configs[1]'s (triangle, tile) pairs and 87 % of the stress frame's are such, ear-clipped slivers whose boxes cross the tile.
+    bool misses = false;
+    if (overlaps && q0.x == (uint32_t)SRT_PRIM_TRIANGLE) {
+      const float t[6] = {__uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)};
+      const double cpx[2] = {colx[max(bb.x, sx0) - sx0], colx[min(bb.z, sx1) - sx0]}, cpy[2] = {rowy[max(bb.y, sy0) - sy0], rowy[min(bb.w, sy1) - sy0]};
+      misses = triangle_misses_corners(t, cpx, cpy);
+    }
+    mask &= ~__ballot(misses);
+    if (mask != 0ull && !touched) {                      // (uniform) the first primitive that reaches this tile: clear_target
+      for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
+      touched = true;
+      __syncthreads();
     }
 
     while (mask) {  // ascending bit order == stream order
@@ -625,29 +646,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
         const double k0 = e0y * d0x, k1 = e1y * d1x, k2 = e2y * d2x;
         const bool xin = (lx >= rx0) && (lx <= rx1);
 
-        // Does the triangle miss the whole rectangle?  Each edge function, as the reference rounds it - (float)(fl64(e.x * fl64(p.y - v.y))
-        // - fl64(e.y * fl64(p.x - v.x))) - is monotone in the sample's column and in its row (every rounding is a non-decreasing map),
-        // so over the rectangle it lies between its values at the four corners.  If every edge keeps one strict sign there, well away
-        // from zero (the sign products of inside_triangle then cannot underflow to a zero that passes both tests), and the three signs
-        // are not all equal, no sample of the rectangle is covered and the row loop is skipped.  Worth its ~90 instructions when the
-        // rectangle has six rows or more: the stress frame's slivers each box most of the target and cover 0.2 % of what they test.
-        bool misses = false;
-        if (ry1 - ry0 >= 5) {
-          const double pya = rowy[ry0], pyb = rowy[ry1];
-          const float ca[3] = {(float)(e0x * (pya - ay) - k0), (float)(e1x * (pya - by) - k1), (float)(e2x * (pya - cy) - k2)};
-          const float cz[3] = {(float)(e0x * (pyb - ay) - k0), (float)(e1x * (pyb - by) - k1), (float)(e2x * (pyb - cy) - k2)};
-          bool pos[3], neg[3];
-#pragma unroll
-          for (int e = 0; e < 3; e++) {          // lanes rx0 and rx1 (row parity 0) hold the rectangle's first and last column
-            const float v0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ca[e]), rx0)), v1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ca[e]), rx1));
-            const float v2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cz[e]), rx0)), v3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cz[e]), rx1));
-            pos[e] = v0 > 1e-18f && v1 > 1e-18f && v2 > 1e-18f && v3 > 1e-18f;      // (false for NaN)
-            neg[e] = v0 < -1e-18f && v1 < -1e-18f && v2 < -1e-18f && v3 < -1e-18f;
-          }
-          misses = (pos[0] || neg[0]) && (pos[1] || neg[1]) && (pos[2] || neg[2]) && !(pos[0] && pos[1] && pos[2]) && !(neg[0] && neg[1] && neg[2]);
-        }
-
-        for (int row = misses ? ry1 + 1 : ry0 + lrow; row <= ry1; row += 2) {
+        for (int row = ry0 + lrow; row <= ry1; row += 2) {
           const double py = rowy[row];
           const double d0y = py - ay, d1y = py - by, d2y = py - cy;
           const float c1 = (float)(e0x * d0y - k0);
@@ -874,40 +873,16 @@ struct srt_raster {
 
 namespace {
 
-// Tile height for this frame.  8-sample-high tiles (more waves per CU) win when the primitives are small or the target has too
-// few 16-high tiles to fill the chip (512^2 x 2: 1.46 -> 0.97 ms on the stress SVG); frames of large primitives on a big
-// target double their (primitive, tile) entries with the smaller tiles and are better off with 16 (1024^2 x 4 stress SVG:
-// 6.9 vs 7.6 ms).  Decided on the host from the target size and the mean bounding-box area of a sample of the stream; the
-// image does not depend on it.
+// Tile height for this frame: 8 sample rows (more waves per CU, 24 with the image-free build) whenever the sample rate allows it.
+// Frames of large primitives used to be better off with 16-high tiles - half the (primitive, tile) pairs - while every pair cost
+// a turn of the ordered loop; since the pairs that cover nothing are dropped 64 at a time in the list scan that no longer holds
+// (stress SVG 1024^2 x 4: 1.40 ms with 8 rows, 1.54 with 16; BASELINE configs[1]: 0.116 / 0.139).  The image does not depend on it.
 uint32_t choose_tile_height(const srt_raster* r) {
   const uint32_t sr = r->P.sr;
   if (sr > 16) return TS;
   if (sr > 8) return 16;
   if (const char* e = getenv("SRT_RASTER_TSY")) { const uint32_t v = (uint32_t)atoi(e); if ((v == 8 || v == 16 || v == 32) && sr <= v) return v; }   // experiments
-  const uint64_t tiles16 = (uint64_t)r->P.tiles_x * ((r->P.h + 16 / sr - 1) / (16 / sr));
-  if (tiles16 < 8192) return 8;
-  const size_t n = r->pending_n;
-  if (n == 0) return 8;
-  const size_t step = n > 2048 ? n / 2048 : 1;
-  double area = 0.0; size_t seen = 0;
-  for (size_t i = 0; i < n; i += step, seen++) {
-    const srt_prim& p = r->pending[i];
-    if (p.kind == SRT_PRIM_POINT) { area += 1.0; continue; }
-    if (p.kind == SRT_PRIM_LINE) {                         // two pixels wide along its longer extent
-      const float dx = std::fabs(p.v.tri[2] - p.v.tri[0]), dy = std::fabs(p.v.tri[3] - p.v.tri[1]);
-      const float len = dx < dy ? dy : dx;
-      if (len == len) area += 2.0 * std::min((double)len, (double)std::max(r->P.w, r->P.h));
-      continue;
-    }
-    float x0 = p.v.tri[0], x1 = p.v.tri[0], y0 = p.v.tri[1], y1 = p.v.tri[1];
-    const int nv = p.kind == SRT_PRIM_TRIANGLE ? 3 : 2;
-    for (int k = 1; k < nv; k++) { x0 = std::min(x0, p.v.tri[2 * k]); x1 = std::max(x1, p.v.tri[2 * k]); y0 = std::min(y0, p.v.tri[2 * k + 1]); y1 = std::max(y1, p.v.tri[2 * k + 1]); }
-    x0 = std::max(x0, 0.0f); y0 = std::max(y0, 0.0f); x1 = std::min(x1, (float)r->P.w); y1 = std::min(y1, (float)r->P.h);
-    if (x1 > x0 && y1 > y0) area += (double)(x1 - x0) * (double)(y1 - y0);
-  }
-  const double mean_samples = area / (double)seen * (double)sr * (double)sr;
-  return mean_samples > 32768.0 ? 16u : 8u;                // (sixty-four 32 x 16 tiles' worth; BASELINE configs[1] - ~9 k samples per
-                                                           //  bounding box - is 9 % faster with 8-high tiles, the stress frame 8 % with 16)
+  return 8;
 }
 
 template <typename T>
