@@ -839,6 +839,9 @@ struct srt_raster {
   std::vector<srt_prim> uploaded;   // what d_prims holds (host copy): an identical resubmission uploads and bins nothing
   bool dirty = true;                // pending differs from d_prims
   hipEvent_t upload_done = nullptr; bool upload_pending = false;   // the DMA out of `pending` may still be reading it
+  // `reserved` words of `pending` that hold device-side indices (a line's ordinal, an image's ImageAux) while that DMA runs, with
+  // the caller's values: put back by settle_upload() once the copy has read them, before anything looks at `pending` again
+  std::vector<std::pair<size_t, uint32_t>> patched;
   srt_prim* d_prims = nullptr;
   int4* d_bbox = nullptr;
   size_t d_cap = 0;
@@ -895,7 +898,16 @@ int grow(T** buf, size_t* cap, size_t need) {
   return SRT_OK;
 }
 
+// Before `pending` is read or rewritten on the host: the upload out of it has finished, its records are the caller's again.
+int settle_upload(srt_raster* r) {
+  if (r->upload_pending) { SRT_HIP(hipEventSynchronize(r->upload_done)); r->upload_pending = false; }
+  for (auto& pr : r->patched) r->pending[pr.first].reserved = pr.second;   // the host copy keeps texture ids / the caller's zeros
+  r->patched.clear();
+  return SRT_OK;
+}
+
 int upload_stream(srt_raster* r) {
+  { const int st = settle_upload(r); if (st != SRT_OK) return st; }
   const size_t n = r->pending_n;
   if (n > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 2^32-1 primitives in one frame");
   {
@@ -924,12 +936,14 @@ int upload_stream(srt_raster* r) {
     SRT_HIP(hipMalloc(&r->d_bbox, cap * sizeof(int4)));
     r->d_cap = cap;
   }
-  r->uploaded.clear();                                 // (until the copy below has been issued: d_prims holds nothing known)
+  // what d_prims is about to hold, as the caller wrote it (the next frame's stream is compared with this); dropped again on every
+  // failure below - without it the next frame just uploads
+  try { r->uploaded.assign(r->pending, r->pending + n); } catch (...) { r->uploaded.clear(); }
   // SRT_PRIM_IMAGE records: per-image constants and loop-value tables (ImageAux); SRT_PRIM_LINE records: their ordinal.
   // The device copy of such a record carries the index of its ImageAux / LineAux in `reserved`.
   std::vector<ImageAux> aux;
   std::vector<float> tabs;
-  std::vector<std::pair<size_t, uint32_t>> patched;   // (record, original reserved)
+  std::vector<std::pair<size_t, uint32_t>>& patched = r->patched;   // (record, original reserved); empty here (settle_upload)
   const RasterParams& P = r->P;
   const float qnan = std::numeric_limits<float>::quiet_NaN();
   uint32_t nlines = 0;
@@ -942,7 +956,7 @@ int upload_stream(srt_raster* r) {
     }
     if (p.kind != SRT_PRIM_IMAGE) continue;
     if (p.reserved >= r->textures.size()) {
-      for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;
+      r->uploaded.clear(); (void)settle_upload(r);
       return srt::fail(SRT_ERR_INVALID, "primitive %zu refers to texture %u, %zu textures are loaded", i, p.reserved, r->textures.size());
     }
     const srt_raster::Tex& T = r->textures[p.reserved];
@@ -999,7 +1013,7 @@ int upload_stream(srt_raster* r) {
       ry = walk(y0, y1, P.ssh, A.ytab, A.by0, A.by1);
     }
     if (tabs.size() > 0xFFFFFFFFull || rx < 0 || ry < 0) {
-      for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;
+      r->uploaded.clear(); (void)settle_upload(r);
       if (tabs.size() > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "image tables exceed 2^32 entries");
       return srt::fail(SRT_ERR_UNSUPPORTED, "image primitive %zu: extent (%g, %g)-(%g, %g) samples is outside what the reference's float loops can walk",
                        i, (double)x0, (double)y0, (double)x1, (double)y1);
@@ -1011,14 +1025,17 @@ int upload_stream(srt_raster* r) {
   }
   // (an intery table never holds more than one entry per line and pixel column / row of the target)
   const bool lines_fit = (uint64_t)nlines * std::max(P.w, P.h) < (1ull << 32);
+  // one DMA transfer out of the pinned buffer; nobody waits for it here - the patched `reserved` words stay as they are until the
+  // host next touches `pending` (settle_upload; the wait per frame for this copy was 9 us of BASELINE configs[1]'s 0.32 ms redraw)
   hipError_t up = hipSuccess;
-  if (n && lines_fit) up = hipMemcpyAsync(r->d_prims, r->pending, n * sizeof(srt_prim), hipMemcpyHostToDevice, r->stream);
-  if (up == hipSuccess && !patched.empty()) up = hipStreamSynchronize(r->stream);   // the records are restored below: the copy must have read them
-  else if (up == hipSuccess && n && lines_fit) { up = hipEventRecord(r->upload_done, r->stream); r->upload_pending = up == hipSuccess; }
-  for (auto& pr : patched) r->pending[pr.first].reserved = pr.second;   // the host copy keeps texture ids / the caller's zeros
+  if (n && lines_fit) {
+    up = hipMemcpyAsync(r->d_prims, r->pending, n * sizeof(srt_prim), hipMemcpyHostToDevice, r->stream);
+    if (up == hipSuccess) { up = hipEventRecord(r->upload_done, r->stream); r->upload_pending = up == hipSuccess; }
+    if (up != hipSuccess) (void)hipStreamSynchronize(r->stream);       // (an event that could not be recorded: wait the plain way)
+  }
+  if (up != hipSuccess || !lines_fit) { r->uploaded.clear(); (void)settle_upload(r); }
   SRT_HIP(up);
   if (!lines_fit) return srt::fail(SRT_ERR_UNSUPPORTED, "%u lines on a %u x %u target: their tables could exceed 2^32 entries", nlines, P.w, P.h);
-  try { r->uploaded.assign(r->pending, r->pending + n); } catch (...) { r->uploaded.clear(); }   // (without the copy the next frame just uploads again)
   r->nlines = nlines;
   r->has_images = !aux.empty();
   if (nlines) {
@@ -1300,7 +1317,7 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
 
 int srt_raster_clear(srt_raster* r) {
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear: NULL context");
-  if (r->upload_pending) { SRT_HIP(hipEventSynchronize(r->upload_done)); r->upload_pending = false; }   // (the pinned stream buffer is about to be rewritten)
+  { const int st = settle_upload(r); if (st != SRT_OK) return st; }   // (the pinned stream buffer is about to be rewritten)
   r->pending_n = 0;
   r->dirty = true;
   r->resolved = false;
@@ -1314,7 +1331,7 @@ int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n) {
   for (size_t i = 0; i < n; i++)
     if (prims[i].kind != SRT_PRIM_TRIANGLE && prims[i].kind != SRT_PRIM_POINT && prims[i].kind != SRT_PRIM_IMAGE && prims[i].kind != SRT_PRIM_LINE)
       return srt::fail(SRT_ERR_INVALID, "primitive %zu has unknown kind %u", i, prims[i].kind);
-  if (r->upload_pending) { SRT_HIP(hipEventSynchronize(r->upload_done)); r->upload_pending = false; }
+  { const int st = settle_upload(r); if (st != SRT_OK) return st; }
   if (r->pending_n + n > r->pending_cap) {
     SRT_HIP(hipSetDevice(r->device));
     SRT_HIP(hipStreamSynchronize(r->stream));      // (an upload may still be reading the old buffer)
