@@ -282,3 +282,37 @@ def test_unwalkable_lines_are_refused(srt):
         got, _, _ = render(srt, one(xy), w, h, sr)
         want, _, _ = H.oracle_raster_frame(one(xy), w, h, sr)
         assert np.array_equal(got, want)
+
+
+def test_appending_and_retargeting_after_a_frame(srt):
+    """The upload patches a line's ordinal / an image's table index into the pinned copy of the stream and puts the caller's words
+    back only when the host next touches that copy (raster.hip: settle_upload).  Two sequences that depend on it: (1) submit,
+    resolve, submit MORE without clearing, resolve - the second upload reads the first part again and needs the texture ids,
+    not the table indices; (2) submit, resolve, change the sample rate, resolve - the same pinned stream is uploaded again."""
+    from _cases import image_stream, line_stream
+
+    w, h = 75, 58
+    img, level0 = image_stream(4242, w, h)
+    tex = H.Textures.from_level0(level0, H.oracle_generate_mips)
+    first = np.concatenate([img, line_stream(77, w, h)])
+    more = np.concatenate([line_stream(78, w, h), img[::-1]])
+    ren = srt.SoftwareRenderer(0)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(2)
+    for t in range(len(tex)):
+        ren.add_texture(tex.texture(t))
+    ren.clear_target()
+    ren.submit(first)
+    a = ren.resolve().copy()
+    want_a, _, _ = H.oracle_raster_frame(first, w, h, 2, textures=tex)
+    assert np.array_equal(a, want_a)
+    ren.submit(more)                                  # (1) appended to the frame already drawn
+    b = ren.resolve().copy()
+    want_b, _, _ = H.oracle_raster_frame(np.concatenate([first, more]), w, h, 2, textures=tex)
+    assert np.array_equal(b, want_b)
+    ren.set_sample_rate(3)                            # (2) same stream, another sample rate
+    c = ren.resolve().copy()
+    want_c, _, _ = H.oracle_raster_frame(np.concatenate([first, more]), w, h, 3, textures=tex)
+    assert np.array_equal(c, want_c)
+    assert np.array_equal(ren.draw_stream(first), H.oracle_raster_frame(first, w, h, 3, textures=tex)[0])
+    ren.close()
