@@ -81,15 +81,19 @@ int dropin_raster_session(const char* path, int device, uint32_t w, uint32_t h, 
   return 0;
 }
 
-// Wall time of DrawSVG's redraw through the drop-in class - what SURVEY.md 8(d) calls the `draw_svg` wall, for bench.py.
+// Wall time of DrawSVG's redraw through the drop-in class, for bench.py.
 // The session is set up as in dropin_raster_session; then `frames` redraws are timed twice:
-//   ms_out[0]  the view moves every frame (the viewbox is nudged, as a pan does): stream build on the host, upload, setup,
-//              binning, tiles, resolve and the read-back into DrawSVG's framebuffer
-//   ms_out[1]  the view stays (an expose / key event): the stream is rebuilt and found unchanged, the tile kernel and the
-//              read-back remain
-//   ms_out[2]  of ms_out[0], the host's share: SvgStreamBuilder::build alone (element walk, transforms, triangulation)
+//   ms_out[0]  the view moves every frame (the viewbox is nudged, as a pan does): the whole of DrawSVG::redraw - the application's
+//              clear() (a 4 x w x h memset in the base class, not the renderer's code), set_svg_2_screen, draw_svg
+//   ms_out[1]  the same with the view unchanged (an expose / key event): the stream is rebuilt and found identical, the tile
+//              kernel and the read-back remain
+//   ms_out[2]  the host's share of a draw_svg: SvgStreamBuilder::build alone (element walk, transforms, cached triangulation)
+//   ms_out[3]  of ms_out[0], the time inside software_renderer->draw_svg() - what SURVEY.md 8(d) calls the `draw_svg` wall
+//              (clear + fill + resolve): stream build on the host, upload, setup, binning, tiles, resolve and the read-back into
+//              DrawSVG's framebuffer
+//   ms_out[4]  of ms_out[1], likewise
 // rgba_out (w*h*4) receives the framebuffer after a final redraw in the ORIGINAL view (the golden's).
-int dropin_raster_bench(const char* path, int device, uint32_t w, uint32_t h, uint32_t sample_rate, uint32_t frames, double ms_out[3],
+int dropin_raster_bench(const char* path, int device, uint32_t w, uint32_t h, uint32_t sample_rate, uint32_t frames, double ms_out[5],
                         uint8_t* rgba_out) {
   SVG* svg = new SVG();
   if (SVGParser::load(path, svg) < 0) return -1;
@@ -110,25 +114,32 @@ int dropin_raster_bench(const char* path, int device, uint32_t w, uint32_t h, ui
   norm_to_screen(0, 0) = scale; norm_to_screen(0, 2) = (w - scale) / 2;
   norm_to_screen(1, 1) = scale; norm_to_screen(1, 2) = (h - scale) / 2;
   for (size_t rate = 2; rate <= sample_rate; rate++) software_renderer->set_sample_rate(rate);
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double inside = 0.0;                                   // time spent in draw_svg() itself
   auto redraw = [&]() {
     software_renderer->clear_target();
     Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
     software_renderer->set_svg_2_screen(m_imp);
+    const double t0 = now();
     software_renderer->draw_svg(*svg);
+    inside += now() - t0;
   };
-  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int k = 0; k < 3; k++) redraw();
+  inside = 0.0;
   double t = now();
   for (uint32_t k = 0; k < frames; k++) {
     viewport->set_viewbox(sw / 2 + 0.37f * (float)(k % 5), sh / 2 - 0.21f * (float)(k % 3), span);   // a pan of a fraction of a pixel per frame
     redraw();
   }
   ms_out[0] = (now() - t) / frames;
+  ms_out[3] = inside / frames;
   viewport->set_viewbox(sw / 2, sh / 2, span);
   redraw();
+  inside = 0.0;
   t = now();
   for (uint32_t k = 0; k < frames; k++) redraw();
   ms_out[1] = (now() - t) / frames;
+  ms_out[4] = inside / frames;
   {
     SvgStreamBuilder builder;
     Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();

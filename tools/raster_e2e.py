@@ -11,12 +11,12 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 svg = sys.argv[2] if len(sys.argv) > 2 else os.path.join(H.GOLDEN, "svg", "test3.svg")
 w, h, sr = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (1024, 1024, 4)
 lib = ctypes.CDLL(os.path.join(H.ORACLE_DIR, "_ref", "libdropin_raster.so"))
-ms = (ctypes.c_double * 3)()
+ms = (ctypes.c_double * 5)()
 out = np.zeros((h, w, 4), np.uint8)
 for rep in range(3):
     rc = lib.dropin_raster_bench(svg.encode(), 0, w, h, sr, frames, ms, H.P(out))
     assert rc == 0, rc
-    print(f"draw_svg wall {ms[0]:.4f} ms   unchanged view {ms[1]:.4f} ms   host stream build {ms[2]:.4f} ms", flush=True)
+    print(f"redraw wall {ms[0]:.4f} ms (inside draw_svg {ms[3]:.4f})   unchanged view {ms[1]:.4f} ms (inside draw_svg {ms[4]:.4f})   host stream build {ms[2]:.4f} ms", flush=True)
 ph = (ctypes.c_double * 5)()
 if hasattr(lib, "dropin_raster_phases") and lib.dropin_raster_phases(svg.encode(), 0, w, h, sr, frames, ph) == 0:
     print("phases (ms): application memset %.4f  stream build %.4f  clear + submit %.4f  resolve (upload, kernels, read-back, wait) %.4f  redraw %.4f" % tuple(ph))
