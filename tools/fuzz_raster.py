@@ -18,7 +18,7 @@ t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(1, 140)), int(rng.integers(1, 120))
-    sr = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 16]))
+    sr = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 16, 20, 32]))
     parts = [random_triangles(seed, int(rng.integers(0, 120)), w, h, float(rng.choice([2.0, 15.0, 60.0, 400.0])))]
     if rng.random() < 0.5:
         parts.append(adversarial_stream(seed, w, h))
