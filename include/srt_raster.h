@@ -105,12 +105,18 @@ int srt_raster_submit(srt_raster* r, const srt_prim* prims, size_t n);
 /* Textures for SRT_PRIM_IMAGE records (CMU462::Texture, D/src/texture.h:24-28): a mip chain of 1..14 RGBA8
  * levels as Sampler2D::generate_mips left it (level k is widths[k] x heights[k], row-major, 4 bytes per texel;
  * the library copies the texels).  The id (0, 1, ... in call order) goes into the record's `reserved` field.
- * Textures stay loaded across frames until srt_raster_clear_textures.  Sampling is the reference's
+ * Textures stay loaded across frames until srt_raster_clear_textures.  Residency: clearing only forgets the SET; the texels stay
+ * in the library's pinned copy and on the device, and a frame that re-adds the same levels in the same order (what DrawSVG's
+ * redraw does every frame, drawsvg.cpp:462-474 having built the chains once) costs one compare per level and uploads nothing -
+ * a stream of unchanged image records on an unchanged target then takes the identical-stream shortcut like any other.
+ * Sampling is the reference's
  * Sampler2DImp::sample_trilinear (texture.cpp:171-193); texels it indexes past the end of a level (undefined in
  * the reference: column `width` / row `height` at the right / bottom border) read as zero. */
 int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widths, const uint32_t* heights,
                            const uint8_t* const* level_texels, uint32_t* id_out);
 int srt_raster_clear_textures(srt_raster* r);
+/* Diagnostic: bytes of texels uploaded to the device by this context so far (tests: a redraw of unchanged textures adds 0). */
+int srt_raster_texture_upload_bytes(srt_raster* r, uint64_t* total);
 
 /* Rasterize the pending stream in order, box-filter resolve, and write width*height RGBA8
  * (row 0 = top, row-major) into host memory `rgba8_out`. Synchronous: the buffer is complete on return. */
@@ -119,8 +125,12 @@ int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out);
 /* Optional: tell the library that `host_rgba8` (bytes >= width*height*4) is the buffer srt_raster_resolve will be
  * handed from now on - DrawSVG lends one framebuffer per window size (set_render_target, drawsvg.cpp:107-114).  The
  * pages are pinned (hipHostRegister), so the read-back of a frame is one DMA transfer instead of a staged pageable
- * copy.  srt_raster_resolve works with any pointer; a bound one is only faster.  Unbind (or bind another buffer, or
- * destroy the context) BEFORE the memory is freed.  Binding NULL unbinds. */
+ * copy.  srt_raster_resolve works with any pointer; a bound one is only faster.  The registration is released by the next
+ * bind (of another buffer or of NULL) or by srt_raster_destroy.  Preferably do that before the memory is freed; DrawSVG cannot
+ * (DrawSVG::resize resizes its framebuffer vector BEFORE it calls set_render_target, drawsvg.cpp:111-114), and that order is
+ * tolerated: releasing a registration removes the runtime's record of the pinned pages and never dereferences the range, and
+ * srt_raster_resolve never uses a bound pointer other than the one it is handed.  What must not happen is a resolve INTO a
+ * buffer that has been freed - which the reference's own renderer would not survive either. */
 int srt_raster_bind_output(srt_raster* r, uint8_t* host_rgba8, size_t bytes);
 
 /* Same as srt_raster_resolve but leaves the RGBA8 image in device memory (pointer valid until the next

@@ -95,6 +95,7 @@ def load_library() -> ctypes.CDLL:
     lib.srt_raster_sync.argtypes = [c_void_p]
     lib.srt_raster_bind_output.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.srt_raster_invalidate.argtypes = [c_void_p]
+    lib.srt_raster_texture_upload_bytes.argtypes = [c_void_p, POINTER(ctypes.c_uint64)]
     _bind_pathtracer(lib)
     _lib = lib
     return lib
@@ -229,6 +230,12 @@ class SoftwareRenderer:
 
     def clear_textures(self) -> None:
         _check(self._lib, self._lib.srt_raster_clear_textures(self._ctx))
+
+    def texture_upload_bytes(self) -> int:
+        """Bytes of texels this context has uploaded to the device so far (a redraw of unchanged textures adds none)."""
+        n = ctypes.c_uint64()
+        _check(self._lib, self._lib.srt_raster_texture_upload_bytes(self._ctx, ctypes.byref(n)))
+        return int(n.value)
 
     def resolve(self) -> np.ndarray:
         out = self.render_target

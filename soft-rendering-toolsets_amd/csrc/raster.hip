@@ -14,11 +14,12 @@
 //
 // Execution model: one wavefront (64 lanes) owns one tile of at most 32x32 samples.  The supersample
 // buffer of the reference (16 B/sample, 256 MiB at 1024^2 x 16 spp) is never materialised in HBM: a
-// tile lives in the wave's REGISTERS from clear to resolve - lane = (column lane & 31, row parity lane >> 5)
-// owns the samples of its column in every other row, TSY / 2 float4 values with static indices - passes
-// through LDS once, for the box filter, and only 4 B/pixel leave the CU.  The wave walks its bin's
-// primitive list IN ORDER (painter's algorithm is order dependent), 64 bounding boxes per step, and
-// rasterizes the overlapping ones into its tile.
+// tile lives in LDS from clear to resolve (`tile[TS * TSY]` float4 in raster_tiles: 4 KiB for the 8-row tiles
+// every sample rate up to 8 takes) - lane = (column lane & 31, row parity lane >> 5), two sample rows per
+// iteration - and only 4 B/pixel leave the CU.  (A variant that kept the tile in registers was built, was
+// bit-exact and measured slower)  The wave walks its bin's primitive list IN ORDER
+// (painter's algorithm is order dependent), 64 bounding boxes per step, and rasterizes the overlapping
+// ones into its tile.
 //
 // Numerics: compiled with -ffp-contract=off (the x86-64 reference build has no FMA), IEEE fp32
 // division (hipcc default) and fp32 denormals preserved, so every coverage verdict and every blended
@@ -866,9 +867,18 @@ struct srt_raster {
   uint8_t* bound_out = nullptr;                        // srt_raster_bind_output: the caller's framebuffer, pinned
   // textures (srt_raster_add_texture): host copies, then one device blob with 4-byte aligned levels
   struct Tex { uint32_t nlevels; uint32_t w[SRT_MAX_MIP_LEVELS], h[SRT_MAX_MIP_LEVELS]; size_t off[SRT_MAX_MIP_LEVELS]; };
-  std::vector<Tex> textures;
-  std::vector<uint8_t> texel_blob;
-  bool tex_dirty = true;
+  std::vector<Tex> textures, prev_textures;
+  // The texel blob lives in PINNED host memory and is kept across srt_raster_clear_textures: DrawSVG's redraw clears and re-adds
+  // the same mip chains every frame (drawsvg.cpp:462-474 builds them once per SVG), so a re-added level is COMPARED with what the
+  // blob already holds at that offset instead of copied, and as long as every level matches the device copy stays as it is.
+  uint8_t* texel_blob = nullptr; size_t blob_n = 0, blob_cap = 0;   // blob_n: bytes of the current texture set
+  size_t blob_kept = 0;                                // bytes of the previous set still in the blob behind blob_n (re-add comparison)
+  size_t device_blob_n = 0;                            // d_texels holds texel_blob[0 .. device_blob_n) byte for byte
+  bool tex_dirty = true;                               // the texture set changed since the image tables (ImageAux) were built
+  uint64_t texel_bytes_uploaded = 0;                   // total bytes of texel uploads (srt_raster_texture_upload_bytes)
+  bool aux_valid = false;                              // d_aux / d_tabs belong to the stream on the device, this target and these textures
+  bool rebuilding = false;                             // between srt_raster_clear_textures and the next frame: add_texture compares with prev_textures / the blob
+  bool blob_upload_pending = false;                    // a DMA transfer may still be reading the pinned blob
   uint8_t* d_texels = nullptr; size_t texels_cap = 0;
   ImageAux* d_aux = nullptr; size_t aux_cap = 0;
   float* d_tabs = nullptr; size_t tabs_cap = 0;
@@ -922,7 +932,13 @@ int upload_stream(srt_raster* r) {
   // the same stream again (DrawSVG redraws on every event): nothing to upload, and the bin lists on the device stay valid
   bool has_image = false;
   for (size_t i = 0; i < n && !has_image; i++) has_image = r->pending[i].kind == SRT_PRIM_IMAGE;
-  if (!has_image && !r->tex_dirty && n == r->uploaded.size() && r->P.nprims == (uint32_t)n &&
+  // the texture set as srt_raster_clear_textures / srt_raster_add_texture left it: re-adding the levels the blob already held
+  // changes nothing (add_texture compared them); fewer or more textures than before do
+  if (r->rebuilding) { if (r->textures.size() != r->prev_textures.size()) r->tex_dirty = true; r->rebuilding = false; }
+  r->blob_kept = 0;
+  // A stream without images does not care about the textures (tex_dirty stays set for the next stream that does); one with
+  // images is the same frame only if its tables - target, textures - are the ones on the device.
+  if ((!has_image || (r->aux_valid && !r->tex_dirty)) && n == r->uploaded.size() && r->P.nprims == (uint32_t)n &&
       (n == 0 || std::memcmp(r->pending, r->uploaded.data(), n * sizeof(srt_prim)) == 0)) {
     r->dirty = false;
     return SRT_OK;
@@ -1047,13 +1063,21 @@ int upload_stream(srt_raster* r) {
     if ((st = grow(&r->d_aux, &r->aux_cap, aux.size())) != SRT_OK || (st = grow(&r->d_tabs, &r->tabs_cap, tabs.size())) != SRT_OK) return st;
     SRT_HIP(hipMemcpy(r->d_aux, aux.data(), aux.size() * sizeof(ImageAux), hipMemcpyHostToDevice));
     SRT_HIP(hipMemcpy(r->d_tabs, tabs.data(), tabs.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (r->tex_dirty) {
-      const size_t nb = r->texel_blob.size() ? r->texel_blob.size() : 4;
-      if ((st = grow(&r->d_texels, &r->texels_cap, nb)) != SRT_OK) return st;
-      if (!r->texel_blob.empty()) SRT_HIP(hipMemcpy(r->d_texels, r->texel_blob.data(), r->texel_blob.size(), hipMemcpyHostToDevice));
+    // the texels: only what the device copy does not hold yet (nothing at all when the frame re-added the textures of the last one),
+    // one DMA transfer out of the pinned blob, not waited for (add_texture waits before it rewrites the blob)
+    if (r->texels_cap < r->blob_n || !r->d_texels) {
+      if ((st = grow(&r->d_texels, &r->texels_cap, r->blob_n ? r->blob_n + r->blob_n / 4 : 4)) != SRT_OK) return st;
+      r->device_blob_n = 0;
     }
+    if (r->device_blob_n < r->blob_n) {
+      SRT_HIP(hipMemcpyAsync(r->d_texels + r->device_blob_n, r->texel_blob + r->device_blob_n, r->blob_n - r->device_blob_n, hipMemcpyHostToDevice, r->stream));
+      r->texel_bytes_uploaded += r->blob_n - r->device_blob_n;
+      r->device_blob_n = r->blob_n;
+      r->blob_upload_pending = true;
+    }
+    r->tex_dirty = false;                          // (only here: a stream without images leaves the flag for the next one with images)
   }
-  r->tex_dirty = false;
+  r->aux_valid = !aux.empty();
   r->P.nprims = (uint32_t)n;
   r->dirty = false;
   r->bins_valid = false;                         // another stream: setup and binning run on its first frame
@@ -1155,11 +1179,15 @@ int check_frame(srt_raster* r) {
   return 0;
 }
 
+// How often a frame can legitimately be repeated: check_frame() either doubles coarse_min (4 -> 65536: at most 14 times), or grows
+// the lists / the line table to exactly what the frame reported for the grid it ran with (once per grid each).
+constexpr int kMaxFrameAttempts = 14 * 2 + 4;
+
 // One frame, repeated while its storage has to grow (at most a few times, and only on the first frame of a stream that needs
 // more than every frame before it).  `sync_all`: the caller needs the frame complete on return; otherwise the function only
 // waits when the stream is new (its needs are unknown until a frame has reported them).
 int run_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats, bool sync_all) {
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < kMaxFrameAttempts; attempt++) {
     int st = launch_frame(r, s, dump_samples, stats);
     if (st != SRT_OK) return st;
     if (r->verified && !sync_all) return SRT_OK;
@@ -1237,6 +1265,7 @@ int srt_raster_destroy(srt_raster* r) {
   (void)hipFree(r->d_ltable);
   if (r->h_status) (void)hipHostFree(r->h_status);
   if (r->pending) (void)hipHostFree(r->pending);
+  if (r->texel_blob) (void)hipHostFree(r->texel_blob);
   if (r->upload_done) (void)hipEventDestroy(r->upload_done);
   (void)hipStreamDestroy(r->stream);
   (void)hipGetLastError();
@@ -1252,18 +1281,50 @@ int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widt
   srt_raster::Tex T;
   std::memset(&T, 0, sizeof T);
   T.nlevels = nlevels;
-  size_t total = r->texel_blob.size();
+  size_t total = r->blob_n;
   for (uint32_t k = 0; k < nlevels; k++) {
     if (!widths[k] || !heights[k] || !level_texels[k]) return srt::fail(SRT_ERR_INVALID, "texture level %u is empty", k);
     T.w[k] = widths[k]; T.h[k] = heights[k]; T.off[k] = total;
     total += 4 * (size_t)widths[k] * heights[k];
   }
   if (total > 0xFFFFFFFFull) return srt::fail(SRT_ERR_UNSUPPORTED, "more than 4 GiB of texels");
-  r->texel_blob.reserve(total);
-  for (uint32_t k = 0; k < nlevels; k++)
-    r->texel_blob.insert(r->texel_blob.end(), level_texels[k], level_texels[k] + 4 * (size_t)widths[k] * heights[k]);
+  // Level by level: what the blob still holds of the previous texture set at this offset (srt_raster_clear_textures keeps it) is
+  // adopted when it is the same bytes - a compare instead of a copy, and the device copy stays valid; the first level that differs
+  // ends that: from there on the levels are copied in and uploaded with the next frame that draws an image.
+  for (uint32_t k = 0; k < nlevels; k++) {
+    const size_t bytes = 4 * (size_t)widths[k] * heights[k];
+    if (r->blob_kept >= bytes && std::memcmp(r->texel_blob + r->blob_n, level_texels[k], bytes) == 0) {
+      r->blob_n += bytes; r->blob_kept -= bytes;
+      continue;
+    }
+    r->blob_kept = 0;
+    r->tex_dirty = true;
+    if (r->device_blob_n > r->blob_n) r->device_blob_n = r->blob_n;
+    if (r->blob_upload_pending) {                   // (the transfer of an earlier frame may still be reading the blob)
+      SRT_HIP(hipSetDevice(r->device));
+      SRT_HIP(hipStreamSynchronize(r->stream));
+      r->blob_upload_pending = false;
+    }
+    if (r->blob_n + bytes > r->blob_cap) {
+      SRT_HIP(hipSetDevice(r->device));
+      const size_t cap = std::max(total, (r->blob_n + bytes) * 2);
+      uint8_t* grown = nullptr;
+      if (hipHostMalloc((void**)&grown, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return srt::fail(SRT_ERR_INVALID, "out of pinned host memory for %zu bytes of texels", cap);
+      }
+      if (r->blob_n) std::memcpy(grown, r->texel_blob, r->blob_n);
+      if (r->texel_blob) (void)hipHostFree(r->texel_blob);
+      r->texel_blob = grown; r->blob_cap = cap;
+    }
+    std::memcpy(r->texel_blob + r->blob_n, level_texels[k], bytes);
+    r->blob_n += bytes;
+  }
+  // (same bytes under other dimensions are another texture)
+  const size_t idx = r->textures.size();
+  if (r->rebuilding && (idx >= r->prev_textures.size() || std::memcmp(&r->prev_textures[idx], &T, sizeof T) != 0)) r->tex_dirty = true;
+  if (!r->rebuilding) r->tex_dirty = true;        // a texture added to the set in use
   r->textures.push_back(T);
-  r->tex_dirty = true;
   r->dirty = true;
   if (id_out) *id_out = (uint32_t)r->textures.size() - 1;
   return SRT_OK;
@@ -1271,11 +1332,20 @@ int srt_raster_add_texture(srt_raster* r, uint32_t nlevels, const uint32_t* widt
 
 int srt_raster_clear_textures(srt_raster* r) {
   if (!r) return srt::fail(SRT_ERR_INVALID, "srt_raster_clear_textures: NULL context");
-  if (r->textures.empty()) return SRT_OK;        // (DrawSVG's redraw clears and re-adds the textures of every frame: nothing to forget here)
+  if (r->textures.empty() && !r->rebuilding) return SRT_OK;
+  // DrawSVG's redraw clears and re-adds the textures of every frame: the set is only forgotten here, the texels stay in the blob
+  // (and on the device) until the next frame shows whether they are still the ones in use
+  if (!r->rebuilding) { r->prev_textures.swap(r->textures); r->rebuilding = true; }
   r->textures.clear();
-  r->texel_blob.clear();
-  r->tex_dirty = true;
+  r->blob_kept += r->blob_n;
+  r->blob_n = 0;
   r->dirty = true;
+  return SRT_OK;
+}
+
+int srt_raster_texture_upload_bytes(srt_raster* r, uint64_t* total) {
+  if (!r || !total) return srt::fail(SRT_ERR_INVALID, "srt_raster_texture_upload_bytes: NULL argument");
+  *total = r->texel_bytes_uploaded;
   return SRT_OK;
 }
 
@@ -1312,6 +1382,7 @@ int srt_raster_set_target(srt_raster* r, uint32_t width, uint32_t height, uint32
   r->verified = false;
   r->coarse_min = 4;
   r->dirty = true;                               // (image records carry per-target tables)
+  r->aux_valid = false;
   return SRT_OK;
 }
 
@@ -1391,7 +1462,7 @@ int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out) {
   SRT_HIP(hipSetDevice(r->device));
   if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
   // frame and read-back are enqueued together; one wait.  (A frame whose storage has to grow is repeated: run_frame.)
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < kMaxFrameAttempts; attempt++) {
     int st = launch_frame(r, r->stream, false, false);
     if (st != SRT_OK) return st;
     SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));

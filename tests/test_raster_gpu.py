@@ -200,6 +200,79 @@ def test_images_match_oracle(srt, sr):
     ren.close()
 
 
+def test_textures_added_before_an_image_free_frame(srt):
+    """add_texture, draw a stream WITHOUT image records, then one with them.  The first frame must not mark the
+    textures as uploaded (it uploads nothing); the second samples the right texels.  Then the other orders around it: a texture
+    set replaced between two image-free frames, and an image stream right after a retarget."""
+    from _cases import image_stream
+
+    w, h, sr = 75, 58, 2
+    prims, level0 = image_stream(77, w, h)
+    tex = H.Textures.from_level0(level0, H.oracle_generate_mips)
+    tris = prims[prims["kind"] != 3]
+    assert len(tris) and len(tris) < len(prims)
+    ren = srt.SoftwareRenderer(0)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(sr)
+    for t in range(len(tex)):
+        ren.add_texture(tex.texture(t))
+    assert np.array_equal(ren.draw_stream(tris), H.oracle_raster_frame(tris, w, h, sr)[0])
+    assert ren.texture_upload_bytes() == 0
+    want, _, _ = H.oracle_raster_frame(prims, w, h, sr, textures=tex)
+    assert np.array_equal(ren.draw_stream(prims), want)
+    assert ren.texture_upload_bytes() == int((4 * tex.level_w.astype(np.int64) * tex.level_h).sum())
+    # another texture set (reversed order: other offsets, other texels at offset 0), an image-free frame, then images again
+    rev = H.Textures.from_level0(level0[::-1], H.oracle_generate_mips)
+    ren.clear_textures()
+    for t in range(len(rev)):
+        ren.add_texture(rev.texture(t))
+    assert np.array_equal(ren.draw_stream(tris), H.oracle_raster_frame(tris, w, h, sr)[0])
+    want_rev, _, _ = H.oracle_raster_frame(prims, w, h, sr, textures=rev)
+    assert np.array_equal(ren.draw_stream(prims), want_rev)
+    if len(level0) > 1:
+        assert not np.array_equal(want_rev, want)
+    # retarget: the image tables follow the target, the texels stay
+    before = ren.texture_upload_bytes()
+    ren.set_sample_rate(3)
+    assert np.array_equal(ren.draw_stream(prims), H.oracle_raster_frame(prims, w, h, 3, textures=rev)[0])
+    assert ren.texture_upload_bytes() == before
+    ren.close()
+
+
+def test_texture_residency_across_redraws(srt):
+    """DrawSVG's redraw clears and re-adds every mip chain each frame.  Re-adding the same levels uploads
+    nothing, and the unchanged image stream takes the identical-stream shortcut; one changed texel is seen."""
+    g = np.load(os.path.join(H.GOLDEN, "raster_test7_image_256_ss2.npz"))        # basic/test7.svg, from the reference build
+    w, h, sr = (int(x) for x in g["meta"])
+    prims, tex, golden = g["prims"], H.Textures.from_npz(g), g["rgba"]
+    assert (prims["kind"] == 3).any() and len(tex)
+    ren = srt.SoftwareRenderer(0)
+    ren.set_render_target(None, w, h)
+    ren.set_sample_rate(sr)
+
+    def redraw(t):
+        ren.clear_textures()
+        for k in range(len(t)):
+            ren.add_texture(t.texture(k))
+        return ren.draw_stream(prims).copy()
+
+    assert np.array_equal(redraw(tex), golden)
+    first = ren.texture_upload_bytes()
+    assert first == int((4 * tex.level_w.astype(np.int64) * tex.level_h).sum())
+    for _ in range(3):
+        assert np.array_equal(redraw(tex), golden)
+    assert ren.texture_upload_bytes() == first, "a redraw of unchanged textures uploaded texels"
+    # one texel of the first level changes: it is seen, and the blob goes up again from that level on
+    mod = H.Textures(tex.nlevels, tex.level_w, tex.level_h, tex.level_off, tex.blob.copy())
+    mod.blob[int(mod.level_off[0]):int(mod.level_off[0]) + 4] ^= 0x5A
+    want = H.oracle_raster_frame(prims, w, h, sr, textures=mod)[0]
+    got = redraw(mod)
+    assert np.array_equal(got, want)
+    assert ren.texture_upload_bytes() > first
+    assert np.array_equal(redraw(tex), golden)
+    ren.close()
+
+
 @pytest.mark.parametrize("sr", [1, 2, 3, 4, 5, 8, 16, 32])
 @pytest.mark.parametrize("wh", [(83, 67), (9, 140), (150, 11), (256, 256)])
 def test_lines_match_oracle(srt, sr, wh):
