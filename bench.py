@@ -168,9 +168,10 @@ def raster_bench(device, frames=30, warmup=3):
     """BASELINE configs[1]: basic/test3.svg (1963 triangles + 1992 lines), 1024x1024, supersample 4.
     `value` follows SURVEY.md 8(d): covered fragments per second of the `draw_svg` WALL - DrawSVG's redraw through the drop-in
     class (stream build on the host, upload, setup, binning, tiles, resolve, read-back into the application's framebuffer),
-    measured in oracle/_ref/libdropin_raster.so = SoftwareRendererHIP inside the reference's own DrawSVG sources; without that
-    library (it is built in the authoring container) the same steps through the C ABI from the prebuilt stream.  The device-only
-    figures - a full frame of the resident stream, and the tile kernel alone - are reported beside it."""
+    measured in integration/_build/libdropin_raster.so = SoftwareRendererHIP inside the reference's own DrawSVG sources (an
+    integration harness of the PRODUCT, built in the authoring container; every pixel comes from libsrt_hip.so).  Without that
+    library `value` is null - its definition never changes; the C-ABI wall from the prebuilt stream (`c_abi_wall_ms`, `c_abi_value`) and
+    the device-only figures - a full frame of the resident stream, the tile kernel alone - are always reported under their own keys."""
     import ctypes
     import glob
 
@@ -215,7 +216,7 @@ def raster_bench(device, frames=30, warmup=3):
     ok = ok and bool(np.array_equal(r_rgba, out))
     ren.close()
     # DrawSVG's redraw through the drop-in class
-    dropin, wall = os.path.join(H.ORACLE_DIR, "_ref", "libdropin_raster.so"), None
+    dropin, wall = os.path.join(ROOT, "integration", "_build", "libdropin_raster.so"), None
     svg = os.path.join(H.GOLDEN, "svg", "test3.svg")
     if os.path.exists(dropin) and os.path.exists(svg):
         lib = ctypes.CDLL(dropin)
@@ -225,7 +226,7 @@ def raster_bench(device, frames=30, warmup=3):
             wall = {"draw_svg_wall_ms": ms3[3], "draw_svg_unchanged_view_wall_ms": ms3[4],
                     "redraw_wall_ms": ms3[0], "redraw_unchanged_view_wall_ms": ms3[1], "host_stream_build_ms": ms3[2],
                     "framebuffer_equals_reference_golden": bool(np.array_equal(d_out, g["rgba"])),
-                    "what": "oracle/_ref/libdropin_raster.so: CMU462::SoftwareRendererHIP linked into the reference's DrawSVG sources and driven "
+                    "what": "integration/_build/libdropin_raster.so: CMU462::SoftwareRendererHIP linked into the reference's DrawSVG sources and driven "
                             "like DrawSVG::redraw (clear(), set_svg_2_screen, draw_svg), the view moving every frame.  draw_svg_wall_ms = the "
                             "time inside software_renderer->draw_svg() - SURVEY.md 8(d)'s `draw_svg` wall (clear + fill + resolve): SVG walk "
                             "with cached triangulations on the host, upload, setup, binning, tiles, resolve, 4 MiB read-back into the "
@@ -238,7 +239,7 @@ def raster_bench(device, frames=30, warmup=3):
                 # the same redraw step by step over the C ABI: where the wall time goes (host clock around each step)
                 wall["phases_ms"] = {"application_clear_target_memset": ph[0], "host_stream_build": ph[1], "clear_and_submit": ph[2],
                                      "resolve_upload_kernels_readback_wait": ph[3], "redraw": ph[4]}
-    e2e_ms = wall["draw_svg_wall_ms"] if wall else abi_new_ms
+    e2e_ms = wall["draw_svg_wall_ms"] if wall else None       # (never another quantity under the same key)
     # what binds the tile kernel: vector-instruction issue and LDS, from the committed SQ counter passes of the same kernel sources
     prof, why_not = None, "no committed PMC pass for the rasterizer"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_raster.json")), reverse=True):
@@ -278,12 +279,43 @@ def raster_bench(device, frames=30, warmup=3):
                   "roofline": _raster_roofline(prof, "stress", "raster_tiles<false", sms_tiles, 40.0 * st2.bin_entries + 4.0 * sw * sh),
                   "reference_cpu_s": 22.7, "reference_cpu_source": "BASELINE.md section 2 (survey-time probe, 1 thread)"}
         r2.close()
+    images = None
+    ip = os.path.join(H.GOLDEN, "raster_test7_image_256_ss2.npz")
+    if os.path.exists(ip):     # basic/test7.svg (<image> elements): DrawSVG's redraw clears and re-adds every mip chain each frame
+        gi = np.load(ip)
+        iw, ih, isr = (int(x) for x in gi["meta"])
+        tex = H.Textures.from_npz(gi)
+        r3 = srt_amd.SoftwareRenderer(device)
+        fb3 = np.empty((ih, iw, 4), np.uint8)
+        r3.set_render_target(fb3, iw, ih)
+        r3.set_sample_rate(isr)
+        chains = [tex.texture(k) for k in range(len(tex))]
+
+        def redraw():
+            r3.clear_textures()
+            for c in chains:
+                r3.add_texture(c)
+            return r3.draw_stream(gi["prims"])
+
+        first = redraw().copy()
+        up_first = r3.texture_upload_bytes()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            redraw()
+        img_ms = (time.perf_counter() - t0) * 1e3 / frames
+        images = {"workload": f"DrawSVG basic/test7.svg {iw}x{ih} supersample={isr}: {int((gi['prims']['kind'] == 3).sum())} image records, {len(tex)} textures",
+                  "redraw_wall_ms_through_the_c_abi": img_ms, "texel_bytes_uploaded_first_frame": up_first,
+                  "texel_bytes_uploaded_per_later_redraw": (r3.texture_upload_bytes() - up_first) / frames,
+                  "bit_exact_vs_reference_golden": bool(np.array_equal(first, gi["rgba"]))}
+        ok = ok and images["bit_exact_vs_reference_golden"]
+        r3.close()
     return {
-        "metric": "Mfrags/s triangle fill", "value": st.fragments / (e2e_ms * 1e-3) / 1e6, "unit": "Mfrags/s",
-        "value_is": "covered fragments / draw_svg wall (SURVEY.md 8(d)): " + ("the time inside SoftwareRendererHIP::draw_svg during DrawSVG's redraw, the view "
-                                                                          "moving every frame (draw_svg.redraw_wall_ms adds the application's own clear())"
-                                                                          if wall else "clear + submit + resolve through the C ABI, a new stream every frame"),
+        "images": images,
+        "metric": "Mfrags/s triangle fill", "value": (st.fragments / (e2e_ms * 1e-3) / 1e6) if e2e_ms else None, "unit": "Mfrags/s",
+        "value_is": "covered fragments / draw_svg wall (SURVEY.md 8(d)): the time inside SoftwareRendererHIP::draw_svg during DrawSVG's redraw, the view "
+                    "moving every frame (draw_svg.redraw_wall_ms adds the application's own clear()); null when integration/_build/libdropin_raster.so is absent",
         "wall_ms_per_frame": e2e_ms, "draw_svg": wall,
+        "c_abi_value": st.fragments / (abi_new_ms * 1e-3) / 1e6,
         "c_abi_wall_ms": {"new_stream_every_frame": abi_new_ms, "same_stream": abi_same_ms,
                           "what": "srt_raster_clear + srt_raster_submit + srt_raster_resolve into the pinned framebuffer from Python (ctypes), "
                                   "no SVG walk"},
@@ -294,7 +326,7 @@ def raster_bench(device, frames=30, warmup=3):
                    "triangles": int((g["prims"]["kind"] == 1).sum()), "lines": int((g["prims"]["kind"] == 4).sum()),
                    "points": int((g["prims"]["kind"] == 2).sum()),
                    "fragments": int(st.fragments), "sample_tests": int(st.sample_tests), "bin_entries": int(st.bin_entries)},
-        "sample_tests_per_s": st.sample_tests / (e2e_ms * 1e-3),
+        "sample_tests_per_s": st.sample_tests / ((e2e_ms or abi_new_ms) * 1e-3),
         "bit_exact_vs_reference_golden": ok, "dtype": "f64 edge functions / f32 blend",
         "roofline": roof, "list_bytes": int(st.list_bytes), "stress": stress,
         "cpu_baseline": {"value": int(counts[2]) / cpu_s / 1e6, "unit": "Mfrags/s", "cores": 1,
@@ -369,6 +401,12 @@ def pt_roofline(cnt, rays_per_launch, kernel_ms, doc, why_not, kernel, scratch_b
         out["traffic_frac_of_hbm_peak"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["traffic_over_algorithmic_scratch"] = (traffic / scratch_bytes_per_launch) if scratch_bytes_per_launch else None
         out["l2_hit_rate"] = (doc["TCC_HIT_sum"] / (doc["TCC_HIT_sum"] + doc["TCC_MISS_sum"])) if doc.get("TCC_HIT_sum") else None
+    # the same story as SCALARS on the roofline object itself (a record that keeps only one level of the line still tells it)
+    out["algorithmic_bytes_per_ray"] = bpr
+    out["hbm_algorithmic_frac"] = hbm["frac"]                                  # SURVEY.md 8(d)'s figure over the HBM peak (may exceed 1, see note)
+    out["valu_frac"] = valu["frac_guide"] if valu else None                     # vector-instruction issue over the guide's rate: what binds
+    out["counter_hbm_frac"] = out.get("traffic_frac_of_hbm_peak")               # rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over the HBM peak
+    out["traffic_over_algorithmic"] = out.get("traffic_over_algorithmic_scratch")   # counter bytes / the ray state the kernels must move
     if why_not:
         out["counters"] = why_not
     if extra:
@@ -500,6 +538,86 @@ def cfg5_bench(device, args, steps=4):
     return out
 
 
+def dropin_pt_bench(device, args, samples=256):
+    """The PT::Pathtracer CLASS end to end (VERDICT round 3, item 2): integration/_build/libdropin_pt_full.so - pathtracer_hip.cpp +
+    pathtracer_core.cpp compiled inside the reference's scene layer - renders the Cornell box (five walls, area light, mirror and
+    glass sphere, as Scene_Object instances) through set_params / begin_render / poll in_progress() / get_output(), 1024 x 1024,
+    `samples` spp, the reference's epoch arithmetic for this host's thread count.  Reported next to it: the SAME scene (the
+    harness's dump, read the way the reference's build_scene reads it) through the C ABI from Python with the headline's step -
+    64-spp epochs alternating on two streams, elision on as in the class - and the class's image against that scene rendered
+    epoch by epoch (the reference's epochs, running mean on the host)."""
+    import torch
+
+    import _harness as H
+    import srt_amd
+
+    path = os.path.join(ROOT, "integration", "_build", "libdropin_pt_full.so")
+    if not os.path.exists(path):
+        return {"value": None, "why": "integration/_build/libdropin_pt_full.so is built in the authoring container (make -C integration)"}
+    del device
+    srt_amd.load_library()
+    lib = ctypes.CDLL(path)
+    W = Hh = args.size
+    threads = cpu_cores()
+    rgb = np.zeros((Hh, W, 3), np.float32)
+    cam = np.zeros(18, np.float32)
+    dump = np.zeros(1 << 20, np.uint8)
+    n = ctypes.c_uint64(0)
+    out = (ctypes.c_double * 8)()
+    rc = lib.dropin_pt_full_bench(3, W, Hh, samples, args.depth, 1, threads, ctypes.c_uint64(args.seed), H.P(rgb), H.P(cam), H.P(dump),
+                                  ctypes.c_uint64(dump.size), ctypes.byref(n), out)
+    if rc != 0:
+        return {"value": None, "why": f"dropin_pt_full_bench returned {rc}"}
+    render_s, build_s, epochs, rays, elided, logged, wall_s = (out[i] for i in range(7))
+    scene = H.parse_scene_dump(dump[: n.value].tobytes())
+    scene["camera"] = {"iview": cam[:16].copy(), "vfov": float(cam[16]), "ar": float(cam[17])}
+    # the same scene through the C ABI, the headline's way
+    pt = srt_amd.Pathtracer(0)
+    pt.set_params(W, Hh, samples, args.depth, True)
+    pt.build_scene(scene)
+    pt.set_camera(scene["camera"])
+    pt.set_elision(True)
+    pt.set_tiling(32, 32, 0, 1)
+    _, per_rank, fpt = pt.tile_info()
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    tiles = [torch.zeros(per_rank * fpt, dtype=torch.float32, device=dev) for _ in range(2)]
+    spp = args.spp_per_step
+    steps = max(2, samples // spp)
+    for i in range(2):
+        pt.render_epoch_device(streams[i].cuda_stream, args.seed, i * spp, spp, tiles[i].data_ptr())
+    torch.cuda.synchronize()
+    pt.ray_count(reset=True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pt.render_epoch_device(streams[i % 2].cuda_stream, args.seed, i * spp, spp, tiles[i % 2].data_ptr())
+    torch.cuda.synchronize()
+    abi_s = time.perf_counter() - t0
+    abi_rays, _ = pt.ray_count(reset=True)
+    # the class's image against the reference's epoch scheme on that scene, epoch by epoch through the C ABI
+    spe = max(1, samples // (threads * 10))
+    acc = np.zeros((Hh, W, 3), np.float32)
+    k = s0 = 0
+    while s0 < samples:
+        take = min(spe, samples - s0)
+        k += 1
+        e = pt.render_epoch(args.seed, s0, take)
+        acc += ((e - acc) * (np.float32(1.0) / np.float32(k))).astype(np.float32)
+        s0 += take
+    pt.close()
+    value, abi_value = rays / render_s / 1e6, abi_rays / abi_s / 1e6
+    return {"metric": "Mrays/s", "value": value, "unit": "Mrays/s", "render_s": render_s, "build_scene_s": build_s, "wall_s_begin_render_to_done": wall_s,
+            "samples": samples, "threads_for_the_epoch_arithmetic": threads, "samples_per_epoch": spe, "epochs": int(epochs),
+            "rays": int(rays), "rays_not_traced_dead_ray_elision": int(elided), "log_ray_calls_delivered_to_the_gui": int(logged),
+            "c_abi_value_same_scene": abi_value, "fraction_of_c_abi": value / abi_value,
+            "get_output_equals_epoch_by_epoch_c_abi_render_bit_for_bit": bool(np.array_equal(rgb.view(np.uint32), acc.view(np.uint32))),
+            "config": {"workload": f"PT::Pathtracer (drop-in class inside the reference's scene layer): Cornell box as 8 Scene_Objects, {W}x{Hh}, {samples} spp, "
+                                   f"depth {args.depth}, BVH on; rays = the reference's scene.hit calls (dead-ray elision on, as the class sets it)"},
+            "what": "value = the reference's scene.hit calls of the render / completion_time().second (begin_render's worker: launches of <= 64 spp on two "
+                    "lanes, the reference's epoch means and running mean folded on the device, nothing copied per epoch); c_abi_value_same_scene = "
+                    "srt_pt_render_epoch_device from Python, 64-spp epochs alternating on two streams, same scene, elision on"}
+
+
 def group_bench(args):
     """`--group N[,M,..]`: the in-process multi-GPU path the C++ drop-in uses (srt_pt_create_multi: a context per rank, image tiles
     round-robin, ONE gather per epoch to rank 0) - timed as srt_pt_group_render_epoch_device, per N.  With N devices it is the
@@ -544,8 +662,13 @@ def group_bench(args):
         kms = [m.kernel_time(enable=False) for m in grp.members]
         gms, gn = grp.gather_time(enable=False)
         img = grp.render_epoch(args.seed, 0, spp)                   # the epoch image of sample 0.. (host copy) for the hash
-        sha = hashlib.sha256(img.tobytes()).hexdigest()[:16]
+        full_sha = hashlib.sha256(img.tobytes()).hexdigest()
+        sha = full_sha[:16]
         base_sha = base_sha or sha
+        want = None
+        if (args.scene, W, args.depth, args.seed, spp) == ("cbox", 1024, 8, 0, 64):
+            import _harness as H
+            want = H.load_fullsize().get("cfg4_cbox_1024_64spp")
         # rank 0's kernel against the issue ceiling / SURVEY.md 8(d)'s byte figure, as in the headline (counters only at N = 1)
         rng = np.random.default_rng(1)
         k = 1 << 14
@@ -561,6 +684,8 @@ def group_bench(args):
             "rehearsal_on_one_gpu": len(set(devices)) < n,
             "ms_per_step": elapsed * 1e3 / steps, "value": rays / elapsed / 1e6, "unit": "Mrays/s", "steps": steps,
             "image_sha256_16": sha, "image_equals_n1": sha == base_sha,
+            "image_equals_golden": bool(want and full_sha == want["sha256"]) if want else None,   # the reference build's image of this epoch (tests/golden/pt_fullsize.json)
+            "rccl_communicators": n if grp.uses_rccl() else 0,
             "rank_kernel_ms": [t / max(1, c) for t, c in kms], "exchange_ms": gms / max(1, gn),
             "roofline": pt_roofline(cnt, rays / steps / n, rank0_ms, doc, why_not, "rank 0's dominant kernel", scratch),
         })
@@ -582,6 +707,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the object that times the PT::Pathtracer class end to end")
     ap.add_argument("--no-elision", action="store_true", help="skip the extra pass that measures dead-ray elision")
     ap.add_argument("--no-overlap", action="store_true", help="every step on one stream (no overlap of consecutive launches)")
     ap.add_argument("--group", default=None, metavar="N[,M..]",
@@ -629,6 +755,7 @@ def main():
     kernel_name = {0: "pt_wave_kernel", 1: "pt_wave_kernel", 2: "pt_wave_kernel", 3: "pt_wave_kernel<.., 3, ..> + pt_cast_kernel",
                    4: "pt_wave_kernel<.., 4, ..> + pt_cast_kernel", -1: "pt_unit_kernel", -2: "pt_epoch_kernel"}[form]
     local_tiles, per_rank, fpt = pt.tile_info()
+    per_rank_floats = per_rank * fpt
     shard = TileShard(W, H, 32, 32, rank, world)
     assert (local_tiles, per_rank, fpt) == (len(shard.local), shard.tiles_per_rank, shard.floats_per_tile)
 
@@ -648,6 +775,7 @@ def main():
     acc = torch.zeros(W * H * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     acc_done = [None]
     kernel_events = []
+    gather_events = []
 
     def step(i, timed):
         k = i % nstreams
@@ -668,6 +796,10 @@ def main():
                     gathered[k].copy_(ghost)
             elif world > 1:
                 gather_tiles(tiles[k], gathered[k], world, rank)  # one RCCL gather over xGMI: tile radiance -> rank 0
+            if timed and world > 1 and rank == 0:
+                e2 = torch.cuda.Event(enable_timing=True)          # (e1 .. e2 on rank 0's stream: the exchange incl. waiting for the slowest rank)
+                e2.record(S)
+                gather_events.append((e1, e2))
             if rank == 0:
                 src = gathered[k] if world > 1 else tiles[k]
                 pt.untile_device(S.cuda_stream, src.data_ptr(), image[k].data_ptr())
@@ -699,6 +831,36 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays, cams = pt.ray_count()
+    # One more step THROUGH THE SAME PATH (tiles, gather, un-tiling), outside the clock: seed 0, samples 0 .. 63 - the epoch whose
+    # image the reference build rendered for tests/golden/pt_fullsize.json (cfg4_cbox_1024_64spp).  Every `--gpus N` run says
+    # whether its N ranks and its collective reproduce that image bit for bit.
+    golden = None
+    gkey = "cfg4_cbox_1024_64spp"
+    if args.scene == "cbox" and (W, args.depth) == (1024, 8):
+        import hashlib
+
+        import _harness as harness                     # (H is the image height here)
+        want = harness.load_fullsize().get(gkey)
+        S0 = streams[0]
+        with torch.cuda.stream(S0):
+            pt.render_epoch_device(S0.cuda_stream, 0, 0, 64, tiles[0].data_ptr())
+            if world > 1 and rehearse:
+                host = tiles[0].cpu()
+                ghost = torch.zeros(world * host.numel()) if rank == 0 else None
+                gather_tiles(host, ghost, world, rank)
+                if rank == 0:
+                    gathered[0].copy_(ghost)
+            elif world > 1:
+                gather_tiles(tiles[0], gathered[0], world, rank)
+            if rank == 0:
+                pt.untile_device(S0.cuda_stream, (gathered[0] if world > 1 else tiles[0]).data_ptr(), image[0].data_ptr())
+        torch.cuda.synchronize()
+        if rank == 0:
+            sha = hashlib.sha256(image[0].cpu().numpy().tobytes()).hexdigest()
+            golden = {"image_sha256": sha, "golden": gkey, "golden_sha256": want["sha256"] if want else None,
+                      "image_equals_golden": bool(want and sha == want["sha256"]),
+                      "golden_from": "the reference's PT::Pathtracer compiled from /root/reference (tests/golden/make_pt_fullsize_golden.py), seed 0, samples 0..63"}
+        pt.ray_count(reset=True)
     # the same steps on ONE stream: a step on its own, wall clock (the timed region above overlaps consecutive launches on two streams)
     no_overlap_ms = None
     if nstreams > 1 and world == 1:
@@ -738,8 +900,15 @@ def main():
         c = torch.tensor([rays, cams], dtype=torch.int64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_rays, total_cams = int(c[0]), int(c[1])
+        rank_stats = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(rank_stats, torch.tensor([kernel_ms, epoch_ms, float(rays)], dtype=torch.float64, device=cdev))
+        rank_kernel_ms = [float(t[0]) for t in rank_stats]
+        rank_step_span_ms = [float(t[1]) for t in rank_stats]
+        rank_rays = [int(t[2]) for t in rank_stats]
     else:
         kernel_ms_max, total_rays, total_cams = kernel_ms, rays, cams
+        rank_kernel_ms, rank_step_span_ms, rank_rays = [kernel_ms], [epoch_ms], [rays]
+    gather_ms = (sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)) if gather_events else None
 
     main_sha = main_mean = None
     if rank == 0:
@@ -809,6 +978,13 @@ def main():
                                "one RCCL gather of tile radiance per step") if world > 1 else "none (1 GPU)",
                 "seed": args.seed,
             },
+            # what a multi-GPU record needs to verify and decompose itself: the epoch image against the reference-built golden, every
+            # rank's own kernel time (one launch alone, after the timed region) and step span, the exchange step on rank 0
+            "image_equals_golden": golden["image_equals_golden"] if golden else None, "golden_check": golden,
+            "rank_kernel_ms": rank_kernel_ms, "rank_step_span_ms": rank_step_span_ms, "rank_rays": rank_rays,
+            "gather_ms": gather_ms,
+            "collective": {"backend": (dist.get_backend() if world > 1 else None), "ranks": (dist.get_world_size() if world > 1 else 1),
+                           "is_rccl": bool(world > 1 and not rehearse), "bytes_per_step_to_rank0": (world - 1) * per_rank_floats * 4 if world > 1 else 0},
             "camera_samples_per_s": total_cams / elapsed, "rays": total_rays, "camera_samples": total_cams,
             "rays_per_camera_sample": total_rays / max(1, total_cams),
             "rays_counted": "every scene.hit the reference performs (no ray is elided)",
@@ -827,8 +1003,15 @@ def main():
             out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt)
         if not args.no_cfg5 and world == 1 and args.scene != "cfg5":
             out["cfg5"] = cfg5_bench(local_rank, args)
+            out["cfg5_value"], out["cfg5_ms_per_step"] = out["cfg5"]["value"], out["cfg5"]["ms_per_step"]
+        if not args.no_dropin and world == 1 and args.scene == "cbox":
+            out["dropin"] = dropin_pt_bench(local_rank, args)
+            out["dropin_value"], out["dropin_fraction_of_c_abi"] = out["dropin"].get("value"), out["dropin"].get("fraction_of_c_abi")
         if not args.no_raster and world == 1:
             out["raster"] = raster_bench(local_rank)
+            out["raster_value"], out["raster_wall_ms"] = out["raster"]["value"], out["raster"]["wall_ms_per_frame"]
+            out["raster_c_abi_wall_ms"] = out["raster"]["c_abi_wall_ms"]["new_stream_every_frame"]
+            out["raster_device_ms_per_frame"] = out["raster"]["device_ms_per_frame"]
         print(json.dumps(out), flush=True)
     pt.close()
     if world > 1:

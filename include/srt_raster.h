@@ -24,7 +24,7 @@
  * order is part of the contract: primitives are blended in stream order.
  *
  * Conventions: every entry point returns 0 on success and a negative srt_status on
- * failure; srt_last_error() returns a thread-local message. No exceptions cross the ABI.
+ * failure (the path tracer's render calls also SRT_CANCELLED = 1 after srt_pt_cancel); srt_last_error() returns a thread-local message. No exceptions cross the ABI.
  * The caller owns every host buffer. One context may be used by one thread at a time.
  * There is NO CPU fallback: without a HIP device srt_raster_create fails.
  */
@@ -39,6 +39,7 @@ extern "C" {
 #endif
 
 typedef enum srt_status {
+    SRT_CANCELLED = 1,        /* not an error: srt_pt_cancel cut the call short, its output was not written (srt_pt.h) */
     SRT_OK = 0,
     SRT_ERR_INVALID = -1,     /* bad argument */
     SRT_ERR_NO_DEVICE = -2,   /* no usable HIP device */

@@ -81,7 +81,10 @@ typedef struct {
 } scene_t;
 
 typedef struct { uint64_t state, inc; uint32_t draws; } rng_t;
-typedef struct { const scene_t* s; rng_t rng; counters_t cnt; } ctx_t;
+/* log: where the rays Pathtracer::log_ray receives go (srt_oracle_pt_epoch_rows_log): 10 floats per ray
+ * {point, dir, t, pixel, sample, bounce} - NULL in every other entry point. */
+typedef struct { float* buf; size_t cap, n; } raylog_t;
+typedef struct { const scene_t* s; rng_t rng; counters_t cnt; raylog_t* log; } ctx_t;
 
 /* ------------------------------------------------------------------------------------------------
  * SRT-RNG v1: replaces util/rand.cpp:13-25 (unit / integer / coin_flip).
@@ -980,7 +983,21 @@ static spec sample_direct(ctx_t* c, const shading_t* h) {
     const v3 to_light = sample_area_lights(c, h->pos);
     const v3 chosen = rng_coin(c, 0.5f) ? world_in : to_light;
     ray_t r6 = ray_make(h->pos, chosen, EPS_F, FLT_MAX, 0);
-    (void)rng_coin(c, 0.0005f);                 /* the log_ray coin is always flipped (pathtracer.cpp:148) */
+    /* if(RNG::coin_flip(0.0005f)) log_ray(world_ray_task6, 5.0f);  (pathtracer.cpp:148 -> rays/pathtracer.cpp:191-193 ->
+     * Gui::Widget_Render::log_ray, gui/widgets.cpp:625-628) - the coin is always flipped */
+    if (rng_coin(c, 0.0005f) && c->log) {
+        raylog_t* L = c->log;
+        if (L->n < L->cap) {
+            float* e = L->buf + 10 * L->n;
+            e[0] = r6.point.x; e[1] = r6.point.y; e[2] = r6.point.z;
+            e[3] = r6.dir.x; e[4] = r6.dir.y; e[5] = r6.dir.z;
+            e[6] = 5.0f;
+            e[7] = (float)(uint32_t)(c->rng.inc >> 33);                   /* pixel = y * w + x (exact below 2^24) */
+            e[8] = (float)(uint32_t)((c->rng.inc >> 1) & 0xffffffu);      /* sample */
+            e[9] = (float)(s->max_depth - h->depth);                      /* bounce: the camera ray carries depth = max_depth */
+        }
+        L->n++;
+    }
     spec d6 = pt_trace(c, &r6).emissive;
     const float pdf_area = area_lights_pdf(c, h->pos, to_light);
     const float pdf4 = lambert_pdf(s, h->out_dir);
@@ -1290,6 +1307,32 @@ int srt_oracle_pt_epoch_rows(void* h, uint64_t seed, uint32_t sample_base, uint3
         }
     }
     cnt_out(&c.cnt, counters);
+    return 0;
+}
+
+/* srt_oracle_pt_epoch_rows, and the rays the epoch hands to Pathtracer::log_ray in the order a single-threaded do_trace logs them
+ * (rows, pixels, samples, bounces): log10 = 10 floats per ray {point[3], dir[3], t, pixel, sample, bounce}; *n_logged counts all of
+ * them, also those beyond cap. */
+int srt_oracle_pt_epoch_rows_log(void* h, uint64_t seed, uint32_t sample_base, uint32_t samples, uint32_t y0, uint32_t y1,
+                                 float* img, float* log10, size_t cap, size_t* n_logged) {
+    const scene_t* s = (const scene_t*)h;
+    if (!s->committed || y1 > s->h) return -1;
+    raylog_t L; L.buf = log10; L.cap = log10 ? cap : 0; L.n = 0;
+    ctx_t c; memset(&c, 0, sizeof c); c.s = s; c.log = &L;
+    for (uint32_t j = y0; j < y1; j++) {
+        for (uint32_t i = 0; i < s->w; i++) {
+            spec acc = S(0, 0, 0);
+            size_t sampled = 0;
+            for (uint32_t k = 0; k < samples; k++) {
+                rng_key(&c.rng, seed, j * s->w + i, sample_base + k);
+                spec p = trace_pixel(&c, i, j);
+                if (s_valid(p)) { acc = s_add(acc, p); sampled++; }
+            }
+            if (sampled > 0) acc = s_scale(acc, 1.0f / sampled);
+            if (img) { float* o = img + 3 * ((size_t)j * s->w + i); o[0] = acc.r; o[1] = acc.g; o[2] = acc.b; }
+        }
+    }
+    if (n_logged) *n_logged = L.n;
     return 0;
 }
 

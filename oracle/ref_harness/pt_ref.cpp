@@ -15,7 +15,8 @@
 //     therefore non-deterministic; "a fixed RNG seed" (BASELINE.json north_star) needs a replacement.
 //     RNG::unit/integer/coin_flip below are the SRT-RNG v1 counter-keyed generator that the oracle
 //     and the HIP kernel implement too, re-keyed per (pixel, sample);
-//   * a no-op sink for Gui::Widget_Render::log_ray (the GUI's ray visualiser).
+//   * a sink for Gui::Widget_Render::log_ray (the GUI's ray visualiser) that records what the path tracer hands it
+//     (ref_pt_epoch_rows_log), so that the oracle's and the kernels' ray log is pinned to the reference's calls.
 // -fno-access-control is applied to this translation unit only (oracle/Makefile).
 #include <algorithm>
 #include <atomic>
@@ -86,8 +87,26 @@ bool coin_flip(float p) { return unit() < p; }
 void seed() {}
 }  // namespace RNG
 
-// The GUI's ray log; the path tracer calls it with probability 0.0005 per shading point.
-void Gui::Widget_Render::log_ray(const Ray&, float, Spectrum) {}
+// The GUI's ray log; the path tracer calls it with probability 0.0005 per shading point (student/pathtracer.cpp:148).  The harness
+// records the call's arguments - and which (pixel, sample) was being traced, in call order - when a log is attached.
+namespace {
+struct RayLog { float* buf; size_t cap, n; uint32_t pixel, sample, ordinal; };
+thread_local RayLog* g_log = nullptr;
+}  // namespace
+void Gui::Widget_Render::log_ray(const Ray& ray, float t, Spectrum color) {
+  RayLog* L = g_log;
+  if (!L) return;
+  if (L->n < L->cap) {
+    float* e = L->buf + 13 * L->n;
+    e[0] = ray.point.x; e[1] = ray.point.y; e[2] = ray.point.z;
+    e[3] = ray.dir.x; e[4] = ray.dir.y; e[5] = ray.dir.z;
+    e[6] = t;
+    e[7] = (float)L->pixel; e[8] = (float)L->sample; e[9] = (float)L->ordinal;
+    e[10] = color.r; e[11] = color.g; e[12] = color.b;
+  }
+  L->n++;
+  L->ordinal++;
+}
 
 namespace {
 
@@ -316,6 +335,33 @@ int ref_pt_epoch_rows(void* h, uint64_t seed, uint32_t sample_base, uint32_t sam
       o[0] = acc.r; o[1] = acc.g; o[2] = acc.b;
     }
   }
+  return 0;
+}
+
+// ref_pt_epoch_rows with the ray log attached: log13 = 13 floats per log_ray call {ray.point, ray.dir, t, pixel, sample, ordinal of
+// the call within its sample, color}; *n_logged counts every call, also those beyond cap.
+int ref_pt_epoch_rows_log(void* h, uint64_t seed, uint32_t sample_base, uint32_t samples, uint32_t row0, uint32_t row1, float* img_out,
+                          float* log13, size_t cap, size_t* n_logged) {
+  RefPT* r = (RefPT*)h;
+  const size_t w = r->pt->out_w, hh = r->pt->out_h;
+  RayLog L{log13, log13 ? cap : 0, 0, 0, 0, 0};
+  g_log = &L;
+  for (size_t j = row0; j < row1 && j < hh; j++) {
+    for (size_t i = 0; i < w; i++) {
+      Spectrum acc;
+      size_t sampled = 0;
+      for (uint32_t s = 0; s < samples; s++) {
+        g_rng.key(seed, (uint32_t)(j * w + i), sample_base + s);
+        L.pixel = (uint32_t)(j * w + i); L.sample = sample_base + s; L.ordinal = 0;
+        Spectrum p = r->pt->trace_pixel(i, j);
+        if (p.valid()) { acc += p; sampled++; }
+      }
+      if (sampled > 0) acc *= (1.0f / sampled);
+      if (img_out) { float* o = img_out + 3 * (j * w + i); o[0] = acc.r; o[1] = acc.g; o[2] = acc.b; }
+    }
+  }
+  g_log = nullptr;
+  if (n_logged) *n_logged = L.n;
   return 0;
 }
 

@@ -271,4 +271,4 @@ class SoftwareRenderer:
         _check(self._lib, self._lib.srt_raster_sync(self._ctx))
 
 
-from ._pt_bindings import Pathtracer, PathtracerGroup, Scene  # noqa: E402,F401
+from ._pt_bindings import LOGGED_RAY_DTYPE, Pathtracer, PathtracerGroup, Scene, SrtCancelled  # noqa: E402,F401

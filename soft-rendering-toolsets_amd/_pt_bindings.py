@@ -14,6 +14,16 @@ class PtMaterial(ctypes.Structure):
     _fields_ = [("type", c_uint32), ("a", c_float * 3), ("b", c_float * 3), ("ior", c_float)]
 
 
+# srt_pt_logged_ray (include/srt_pt.h): one call of Pathtracer::log_ray
+LOGGED_RAY_DTYPE = np.dtype([("point", np.float32, 3), ("dir", np.float32, 3), ("t", np.float32), ("pixel", np.uint32),
+                             ("sample", np.uint32), ("bounce", np.uint32)])
+SRT_CANCELLED = 1
+
+
+class SrtCancelled(Exception):
+    """A render call returned SRT_CANCELLED: srt_pt_cancel cut it short, its output was not written."""
+
+
 COUNTER_NAMES = ("rays", "box_tests", "objects_entered", "tri_tests", "sphere_tests", "tlas_nodes", "blas_nodes",
                  "light_tri_tests")
 
@@ -75,6 +85,17 @@ def bind(lib: ctypes.CDLL) -> None:
     lib.srt_pt_tonemap_device.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_float, c_void_p]
     lib.srt_pt_math_div_sqrt.argtypes = [c_void_p, c_void_p, c_size_t, ctypes.c_int, c_void_p]
     lib.srt_pt_sync.argtypes = [c_void_p]
+    lib.srt_pt_cancel.argtypes = [c_void_p]
+    lib.srt_pt_cancel_requested.argtypes = [c_void_p]
+    lib.srt_pt_clear_cancel.argtypes = [c_void_p]
+    lib.srt_pt_set_ray_log.argtypes = [c_void_p, c_uint32]
+    lib.srt_pt_read_ray_log.argtypes = [c_void_p, c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_uint64)]
+    lib.srt_pt_read_ray_log_stream.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_uint64)]
+    lib.srt_pt_group_render_epoch_lane.argtypes = [c_void_p, c_int, c_uint64, c_uint32, c_uint32, POINTER(c_void_p), POINTER(c_void_p)]
+    lib.srt_pt_group_cancel.argtypes = [c_void_p]
+    lib.srt_pt_group_clear_cancel.argtypes = [c_void_p]
+    lib.srt_pt_group_set_ray_log.argtypes = [c_void_p, c_uint32]
+    lib.srt_pt_group_read_ray_log.argtypes = [c_void_p, c_int, c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_uint64)]
 
 
 def _p(a):
@@ -236,12 +257,47 @@ class Pathtracer:
     def render_epoch(self, seed: int, sample_base: int, samples: int, out: np.ndarray | None = None) -> np.ndarray:
         if out is None:
             out = np.zeros((self.out_h, self.out_w, 3), np.float32)
-        self._check(self._lib, self._lib.srt_pt_render_epoch(self._ctx, seed, sample_base, samples, _p(out)))
+        st = self._lib.srt_pt_render_epoch(self._ctx, seed, sample_base, samples, _p(out))
+        if st == SRT_CANCELLED:
+            raise SrtCancelled()
+        self._check(self._lib, st)
         return out
 
     def render_epoch_device(self, stream: int, seed: int, sample_base: int, samples: int, d_tiles_out: int) -> None:
-        self._check(self._lib, self._lib.srt_pt_render_epoch_device(self._ctx, c_void_p(stream), seed, sample_base, samples,
-                                                                    c_void_p(d_tiles_out)))
+        st = self._lib.srt_pt_render_epoch_device(self._ctx, c_void_p(stream), seed, sample_base, samples, c_void_p(d_tiles_out))
+        if st == SRT_CANCELLED:
+            raise SrtCancelled()
+        self._check(self._lib, st)
+
+    # -- Pathtracer::cancel / Pathtracer::log_ray on the C ABI ------------------------------------------
+    def cancel_device(self) -> None:
+        """srt_pt_cancel: may be called from another thread while render_epoch runs."""
+        self._check(self._lib, self._lib.srt_pt_cancel(self._ctx))
+
+    def cancel_requested(self) -> bool:
+        return bool(self._lib.srt_pt_cancel_requested(self._ctx))
+
+    def clear_cancel(self) -> None:
+        self._check(self._lib, self._lib.srt_pt_clear_cancel(self._ctx))
+
+    def set_ray_log(self, capacity: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_set_ray_log(self._ctx, int(capacity)))
+
+    def read_ray_log(self, stream: int | None = None):
+        """(rays as a LOGGED_RAY_DTYPE array in log order, dropped): what Pathtracer::log_ray received since the last read."""
+        n, dropped = c_size_t(), c_uint64()
+        if stream is None:
+            self._check(self._lib, self._lib.srt_pt_read_ray_log(self._ctx, None, 0, ctypes.byref(n), ctypes.byref(dropped)))
+        else:
+            self._check(self._lib, self._lib.srt_pt_read_ray_log_stream(self._ctx, c_void_p(stream), None, 0, ctypes.byref(n), ctypes.byref(dropped)))
+        out = np.zeros(n.value, LOGGED_RAY_DTYPE)
+        got = c_size_t()
+        if stream is None:
+            self._check(self._lib, self._lib.srt_pt_read_ray_log(self._ctx, _p(out) if n.value else None, n.value, ctypes.byref(got), ctypes.byref(dropped)))
+        else:
+            self._check(self._lib, self._lib.srt_pt_read_ray_log_stream(self._ctx, c_void_p(stream), _p(out) if n.value else None, n.value,
+                                                                        ctypes.byref(got), ctypes.byref(dropped)))
+        return out[:got.value], int(dropped.value)
 
     def untile_device(self, stream: int, d_gathered: int, d_image: int) -> None:
         self._check(self._lib, self._lib.srt_pt_untile_device(self._ctx, c_void_p(stream), c_void_p(d_gathered), c_void_p(d_image)))
@@ -451,6 +507,33 @@ class PathtracerGroup:
         d, s = c_void_p(), c_void_p()
         self._check(self._lib, self._lib.srt_pt_group_render_epoch_device(self._g, seed, sample_base, samples, ctypes.byref(d), ctypes.byref(s)))
         return d.value, s.value
+
+    def render_epoch_lane(self, lane: int, seed: int, sample_base: int, samples: int):
+        """As render_epoch_device on lane `lane` (its own streams and buffers): epochs on different lanes overlap."""
+        d, s = c_void_p(), c_void_p()
+        st = self._lib.srt_pt_group_render_epoch_lane(self._g, int(lane), seed, sample_base, samples, ctypes.byref(d), ctypes.byref(s))
+        if st == SRT_CANCELLED:
+            raise SrtCancelled()
+        self._check(self._lib, st)
+        return d.value, s.value
+
+    def cancel_device(self) -> None:
+        self._check(self._lib, self._lib.srt_pt_group_cancel(self._g))
+
+    def clear_cancel(self) -> None:
+        self._check(self._lib, self._lib.srt_pt_group_clear_cancel(self._g))
+
+    def set_ray_log(self, capacity: int) -> None:
+        self._check(self._lib, self._lib.srt_pt_group_set_ray_log(self._g, int(capacity)))
+
+    def read_ray_log(self, lane: int = 0):
+        n, dropped = c_size_t(), c_uint64()
+        self._check(self._lib, self._lib.srt_pt_group_read_ray_log(self._g, int(lane), None, 0, ctypes.byref(n), ctypes.byref(dropped)))
+        out = np.zeros(n.value, LOGGED_RAY_DTYPE)
+        got = c_size_t()
+        self._check(self._lib, self._lib.srt_pt_group_read_ray_log(self._g, int(lane), _p(out) if n.value else None, n.value, ctypes.byref(got),
+                                                                     ctypes.byref(dropped)))
+        return out[:got.value], int(dropped.value)
 
     def gather_time(self, enable: bool = True):
         """(total ms, epochs) of the exchange step (gather + un-tiling, incl. waiting for the slowest rank) since the previous call."""

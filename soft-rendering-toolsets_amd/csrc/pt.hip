@@ -28,6 +28,8 @@
 #include "pt_scene.h"
 #include "srt_common.h"
 #include "srt_pt.h"
+#include "srt_pt_debug.h"
+#include "pt_internal.h"
 
 #include "pt_trace.h"
 #include "pt_wave.h"
@@ -42,7 +44,10 @@ namespace srt {
 // sum is accumulated exactly like do_trace (rays/pathtracer.cpp:216-226).
 __global__ __launch_bounds__(64) void pt_epoch_kernel(DScene S, TileMap T, uint64_t seed, uint32_t sample_base,
                                                       uint32_t samples, float* __restrict__ tiles_out,
-                                                      unsigned long long* __restrict__ ray_counter) {
+                                                      unsigned long long* __restrict__ ray_counter, const uint32_t* host_cancel, uint32_t* dev_cancel) {
+  // srt_pt_cancel: the first block looks at the host's flag, the others at its device copy - blocks that have not started yet end at once
+  if (blockIdx.x == 0u && threadIdx.x == 0u && cancel_requested(host_cancel)) atomicExch(dev_cancel, 1u);
+  if (cancel_raised(dev_cancel)) return;
   const uint32_t px_per_tile = T.tile_w * T.tile_h;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t local_tile = gid / px_per_tile;
@@ -83,7 +88,9 @@ __global__ __launch_bounds__(64) void pt_epoch_kernel(DScene S, TileMap T, uint6
 // that better than registers do (131 k-triangle scene: 325 -> 417 Mrays/s).
 __global__ __launch_bounds__(64, 8) void pt_unit_kernel(DScene S, TileMap T, uint64_t seed, uint32_t sample_base, uint32_t samples,
                                                      uint32_t total_units, float* __restrict__ sample_out,
-                                                     unsigned long long* __restrict__ ray_counter) {
+                                                     unsigned long long* __restrict__ ray_counter, const uint32_t* host_cancel, uint32_t* dev_cancel) {
+  if (blockIdx.x == 0u && threadIdx.x == 0u && cancel_requested(host_cancel)) atomicExch(dev_cancel, 1u);   // (as pt_epoch_kernel)
+  if (cancel_raised(dev_cancel)) return;
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   Counters cnt;
   cnt.v[C_RAYS] = 0;
@@ -333,6 +340,9 @@ struct srt_pt {
     StreamCounters* d_sc = nullptr;
     unsigned long long* d_block_counters = nullptr; size_t block_counters_n = 0;
     uint32_t* d_cast_spill = nullptr; size_t cast_spill_words = 0;   // the ray-cast kernel's traversal frames beyond those in LDS
+    uint32_t* d_cancel = nullptr;                                     // srt_pt_cancel as the kernels of this stream have seen it (sticky until srt_pt_clear_cancel)
+    uint32_t* d_ray_log = nullptr; uint32_t ray_log_cap = 0;          // srt_pt_set_ray_log: this stream's ring (pt_trace.h: log_ray_event)
+    uint32_t last_samples = 0, last_npix = 0;                         // what d_samples holds: samples per pixel and pixel slots of the last launch
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
   int wave_blocks = 0; size_t wave_lds = 0; int wave_mode = -1; const void* wave_kern = nullptr;
@@ -344,6 +354,9 @@ struct srt_pt {
   unsigned long long* d_totals = nullptr;   // C_COUNT instrumented totals + 4 slots: rays of the epoch kernels, rays elided, streamed forms: entries queued, alive slot-generations
   uint32_t* h_fault = nullptr;              // pinned, device-visible: bit 0 = a streamed launch ended with unfinished units (sticky until reported)
   uint32_t* d_fault = nullptr;              // its device address
+  uint32_t* h_cancel = nullptr;             // pinned, device-visible: srt_pt_cancel's flag (any host thread may set it)
+  uint32_t* d_host_cancel = nullptr;        // its device address
+  uint32_t ray_log_cap = 0;                 // srt_pt_set_ray_log: rays per stream and read; 0: Pathtracer::log_ray is not delivered
   int elide = 0;                            // srt_pt_set_elision
   unsigned long long last_counters[C_COUNT] = {0};
   uint64_t camera_samples = 0;
@@ -409,9 +422,10 @@ bool elision_provable(const srt_pt* pt) {
   return true;
 }
 
-DScene device_scene(const srt_pt* pt) {
+DScene device_scene(const srt_pt* pt, const srt_pt::EpochBuffers* B = nullptr) {
   const FlatScene& F = pt->built.flat;
   DScene S;
+  S.ray_log = B ? B->d_ray_log : nullptr; S.ray_log_cap = B ? B->ray_log_cap : 0u;
   S.nodes = pt->d_nodes; S.tris = pt->d_tris; S.tri_nrm = pt->d_nrm; S.objects = pt->d_objects;
   S.lights = pt->d_lights; S.light_tris = pt->d_ltris; S.materials = pt->d_mats;
   S.wave_tlas = pt->d_wave; S.wave_q = (uint32_t)F.wave_tlas.size(); S.blas_recs = pt->d_blas; S.wave_lazy = pt->d_wave_lazy;
@@ -445,6 +459,30 @@ int ensure(T** buf, size_t* have, size_t need) {
   if (*buf) { SRT_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
   SRT_HIP(hipMalloc(buf, need * sizeof(T)));
   *have = need;
+  return SRT_OK;
+}
+
+// The scratch set of stream `s` (created on first use), with what every kernel form needs: the stream's sticky cancel word and,
+// when srt_pt_set_ray_log asked for one, its ray-log ring.
+int stream_buffers(srt_pt* pt, hipStream_t s, srt_pt::EpochBuffers** out) {
+  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  // (hipMemsetAsync ON `s`: a plain hipMemset is ordered on the null stream only, which the callers' non-blocking streams do not wait
+  //  for - a kernel on `s` could still see what the allocation held before)
+  if (!B.d_cancel) {
+    SRT_HIP(hipMalloc(&B.d_cancel, sizeof(uint32_t)));
+    SRT_HIP(hipMemsetAsync(B.d_cancel, 0, sizeof(uint32_t), s));
+  }
+  if (B.ray_log_cap != pt->ray_log_cap) {
+    if (B.d_ray_log) { SRT_HIP(hipStreamSynchronize(s)); SRT_HIP(hipFree(B.d_ray_log)); B.d_ray_log = nullptr; }
+    B.ray_log_cap = 0;
+    if (pt->ray_log_cap) {
+      const size_t words = kRayLogHeader + (size_t)kRayLogWords * pt->ray_log_cap;
+      SRT_HIP(hipMalloc(&B.d_ray_log, words * sizeof(uint32_t)));
+      SRT_HIP(hipMemsetAsync(B.d_ray_log, 0, kRayLogHeader * sizeof(uint32_t), s));
+      B.ray_log_cap = pt->ray_log_cap;
+    }
+  }
+  *out = &B;
   return SRT_OK;
 }
 
@@ -579,13 +617,15 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
   const uint32_t chunk = samples_per_launch(px);
   const uint32_t nlanes = (uint32_t)pt->wave_blocks * 256;
   int st;
-  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  srt_pt::EpochBuffers* Bp = nullptr;
+  if ((st = stream_buffers(pt, s, &Bp)) != SRT_OK) return st;
+  srt_pt::EpochBuffers& B = *Bp;
   if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&B.d_records, &B.records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
   if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   if (!B.d_queue) {
     SRT_HIP(hipMalloc(&B.d_queue, (1 + ST_COUNT_) * sizeof(unsigned long long)));
-    SRT_HIP(hipMemset(B.d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long)));
+    SRT_HIP(hipMemsetAsync(B.d_queue, 0, (1 + ST_COUNT_) * sizeof(unsigned long long), s));   // (on `s`: see stream_buffers)
   }
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
@@ -610,9 +650,10 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.flat_ready = getenv("SRT_FLAT_READY") ? (uint32_t)atoi(getenv("SRT_FLAT_READY")) : kFlatReady;
     P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;
     P.queue_head = B.d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1; P.stamps = B.d_queue + 1;
+    P.host_cancel = pt->d_host_cancel; P.dev_cancel = B.d_cancel;
     if (n) {
       SRT_HIP(hipMemsetAsync(B.d_queue, 0, sizeof(unsigned long long), s));
-      const DScene DS = device_scene(pt);
+      const DScene DS = device_scene(pt, &B);
 #define SRT_LAUNCH_WAVE(STAMP_, TRAV_, DL_, NR_)                                                                              \
   pt_wave_kernel<STAMP_, TRAV_, DL_, NR_><<<dim3(pt->wave_blocks), dim3(256), lds, s>>>(DS, P, DS.objects, DS.tris, DS.tri_nrm,       \
                                                                                    DS.nodes, DS.lights, DS.light_tris,          \
@@ -628,7 +669,8 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
-    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
+    if (d_tiles_out) pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out, B.d_cancel);
+    B.last_samples = n; B.last_npix = px;
     SRT_HIP(hipGetLastError());
     if (samples == 0) break;
   }
@@ -676,7 +718,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
     SRT_HIP(hipFuncSetAttribute(ckern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_CAST_STATS") && !pt->d_cast_stats) {
       SRT_HIP(hipMalloc(&pt->d_cast_stats, CS_COUNT * sizeof(unsigned long long)));
-      SRT_HIP(hipMemset(pt->d_cast_stats, 0, CS_COUNT * sizeof(unsigned long long)));
+      SRT_HIP(hipMemsetAsync(pt->d_cast_stats, 0, CS_COUNT * sizeof(unsigned long long), s));
     }
     if (pt->d_cast_stats) SRT_HIP(hipFuncSetAttribute(ckern_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt->cast_lds));
     if (getenv("SRT_DEBUG")) fprintf(stderr, "[srt] pt_cast_kernel: %d blocks x %d threads, %zu B LDS per block (%u of %u frames per lane), %d waves/CU\n",
@@ -696,14 +738,16 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
   if (logic_lds > 160u * 1024u) return srt::fail(SRT_ERR_UNSUPPORTED, "the streamed sweeps' LDS slots (%zu bytes) do not fit", logic_lds);
   SRT_HIP(hipFuncSetAttribute(lkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)logic_lds));
   const uint32_t chunk = samples_per_launch(px);
-  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  srt_pt::EpochBuffers* Bp = nullptr;
+  if ((st = stream_buffers(pt, s, &Bp)) != SRT_OK) return st;
+  srt_pt::EpochBuffers& B = *Bp;
   if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   if (!B.d_sc) SRT_HIP(hipMalloc(&B.d_sc, sizeof(StreamCounters)));
   const size_t spill_words = (size_t)(depth - pt->cast_lds_frames) * 3u * (size_t)pt->cast_blocks * (size_t)pt->cast_threads;
   if (spill_words && (st = ensure(&B.d_cast_spill, &B.cast_spill_words, spill_words)) != SRT_OK) return st;
   const uint32_t shadow_batches = (uint32_t)((F.delta_lights.size() + 2) / 3);
-  const DScene DS = device_scene(pt);
+  const DScene DS = device_scene(pt, &B);
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
     const uint32_t n = samples - done < chunk ? samples - done : chunk;
     WaveParams P{};
@@ -745,6 +789,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_d; P.hits = B.d_hits; P.sc = B.d_sc;
       P.block_counters = B.d_block_counters;
       P.obj_shift = stream_obj_shift(F);
+      P.host_cancel = pt->d_host_cancel; P.dev_cancel = B.d_cancel;
       SRT_HIP(hipMemsetAsync(B.d_sc, 0, sizeof(StreamCounters), s));
       SRT_HIP(hipMemsetAsync(B.d_state, 0, 2 * (size_t)nlanes * sizeof(uint32_t), s));   // the flags and emit planes: every slot idle
       // generations: list scheduling of units of <= M batches on nlanes slots
@@ -768,6 +813,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       if (C.leaf_min < 1u) C.leaf_min = 1u;
       if (C.object_min < 1u) C.object_min = 1u;
       C.stats = pt->d_cast_stats;
+      C.dev_cancel = B.d_cancel;
       const dim3 lgrid(nblocks), lblock(lthreads);
       const dim3 cgrid((nlanes + kCompactChunk - 1) / kCompactChunk);
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
@@ -793,7 +839,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
 #undef SRT_LAUNCH_LOGIC
 #undef SRT_LAUNCH_PHASE
         if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 1)) != SRT_OK) return st;
-        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id, pt->d_totals + C_COUNT + 2);
+        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id, pt->d_totals + C_COUNT + 2, pt->d_host_cancel, B.d_cancel);
         if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
         C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
         const dim3 kgrid(pt->cast_blocks), kblock(pt->cast_threads);
@@ -802,12 +848,13 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
         if ((st = stream_time_end(pt, s, 2)) != SRT_OK) return st;
       }
       if (pt->stream_timing) pt->stream_generations += gens;
-      pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT, B.d_sc, pt->d_fault);
+      pt_stream_finish_kernel<<<dim3(1), dim3(256), 0, s>>>(B.d_block_counters, nblocks, pt->d_totals + C_COUNT, B.d_sc, pt->d_fault, B.d_cancel);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
-    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
+    if (d_tiles_out) pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out, B.d_cancel);
+    B.last_samples = n; B.last_npix = px;
     SRT_HIP(hipGetLastError());
     if (samples == 0) break;
   }
@@ -820,7 +867,9 @@ int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample
   const uint32_t px = T.local_tiles * T.tile_w * T.tile_h;
   const uint32_t chunk = samples_per_launch(px);
   int st;
-  srt_pt::EpochBuffers& B = pt->epoch_buffers[s];
+  srt_pt::EpochBuffers* Bp = nullptr;
+  if ((st = stream_buffers(pt, s, &Bp)) != SRT_OK) return st;
+  srt_pt::EpochBuffers& B = *Bp;
   if ((st = ensure(&B.d_samples, &B.samples_floats, (size_t)px * chunk * 4)) != SRT_OK) return st;
   if ((st = ensure(&B.d_running, &B.running_floats, (size_t)px * 4)) != SRT_OK) return st;
   for (uint32_t done = 0; done < samples || (samples == 0 && done == 0); done += chunk) {
@@ -828,13 +877,14 @@ int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample
     const uint64_t units = (uint64_t)px * n;
     if (n) {
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
-      pt_unit_kernel<<<dim3((unsigned)((units + 63) / 64)), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base + done, n,
-                                                                              (uint32_t)units, B.d_samples, pt->d_totals + C_COUNT);
+      pt_unit_kernel<<<dim3((unsigned)((units + 63) / 64)), dim3(64), 0, s>>>(device_scene(pt, &B), T, seed, sample_base + done, n,
+                                                                              (uint32_t)units, B.d_samples, pt->d_totals + C_COUNT, pt->d_host_cancel, B.d_cancel);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
     const int first = done == 0, last = done + chunk >= samples;
-    pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out);
+    if (d_tiles_out) pt_reduce_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(T, pt->w, pt->h, n, B.d_samples, B.d_running, first, last, d_tiles_out, B.d_cancel);
+    B.last_samples = n; B.last_npix = px;
     SRT_HIP(hipGetLastError());
     if (samples == 0) break;
   }
@@ -842,6 +892,10 @@ int render_epoch_units(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample
 }
 
 }  // namespace
+
+namespace srt {
+int pt_check_fault(srt_pt* pt, const char* what) { return pt ? check_stream_fault(pt, what) : SRT_OK; }
+}  // namespace srt
 
 extern "C" {
 
@@ -863,11 +917,15 @@ int srt_pt_create(int device, srt_pt** out) {
         hipMalloc(&pt->d_totals, (C_COUNT + 4) * sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void**)&pt->h_fault, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&pt->d_fault, pt->h_fault, 0) != hipSuccess ||
+        hipHostMalloc((void**)&pt->h_cancel, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&pt->d_host_cancel, pt->h_cancel, 0) != hipSuccess ||
         hipMemset(pt->d_totals, 0, (C_COUNT + 4) * sizeof(unsigned long long)) != hipSuccess) {
       delete pt;
       return srt::fail(SRT_ERR_HIP, "HIP context setup failed on device %d", device);
     }
     *pt->h_fault = 0u;
+    *pt->h_cancel = 0u;
+    (void)hipDeviceSynchronize();                         // (the null-stream memset above: done before any non-blocking stream's first kernel)
     pt->device = device;
   }
   *out = pt;
@@ -891,7 +949,9 @@ int srt_pt_destroy(srt_pt* pt) {
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_wave_lazy); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     if (pt->h_fault) (void)hipHostFree(pt->h_fault);
+    if (pt->h_cancel) (void)hipHostFree(pt->h_cancel);
     for (auto& kv : pt->epoch_buffers) {
+      (void)hipFree(kv.second.d_cancel); (void)hipFree(kv.second.d_ray_log);
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
       (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id); (void)hipFree(kv.second.d_cast_spill);
       (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc); (void)hipFree(kv.second.d_block_counters);
@@ -1100,11 +1160,15 @@ int srt_pt_set_kernel(srt_pt* pt, int mode) {
   return SRT_OK;
 }
 
-int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples,
-                               float* d_tiles_out) {
-  int st = need_ready(pt, "srt_pt_render_epoch_device");
+}  // extern "C"
+
+namespace {
+// srt_pt_render_epoch_device (d_tiles_out: the epoch's tile radiance) and srt_pt_render_samples_device (d_tiles_out == NULL: the
+// launch's per-sample radiance stays in the stream's sample buffer for srt_pt_fold_epochs_device).
+int render_device(srt_pt* pt, const char* what, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples, float* d_tiles_out) {
+  int st = need_ready(pt, what);
   if (st != SRT_OK) return st;
-  if (!d_tiles_out) return srt::fail(SRT_ERR_INVALID, "srt_pt_render_epoch_device: output is NULL");
+  if (__atomic_load_n(pt->h_cancel, __ATOMIC_ACQUIRE) != 0u) return SRT_CANCELLED;   // nothing more is enqueued until srt_pt_clear_cancel
   hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream; NULL is the HIP default stream
   const TileMap& T = pt->tiles;
   const uint64_t lanes = (uint64_t)T.local_tiles * T.tile_w * T.tile_h;
@@ -1129,9 +1193,11 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
       if (st != SRT_OK) return st;
     } else {
       const uint32_t blocks = (uint32_t)((lanes + 63) / 64);
+      srt_pt::EpochBuffers* Bp = nullptr;
+      if ((st = stream_buffers(pt, s, &Bp)) != SRT_OK) return st;
       if ((st = time_begin(pt, s)) != SRT_OK) return st;
-      pt_epoch_kernel<<<dim3(blocks), dim3(64), 0, s>>>(device_scene(pt), T, seed, sample_base, samples, d_tiles_out,
-                                                        pt->d_totals + C_COUNT);
+      pt_epoch_kernel<<<dim3(blocks), dim3(64), 0, s>>>(device_scene(pt, Bp), T, seed, sample_base, samples, d_tiles_out,
+                                                        pt->d_totals + C_COUNT, pt->d_host_cancel, Bp->d_cancel);
       SRT_HIP(hipGetLastError());
       if ((st = time_end(pt, s)) != SRT_OK) return st;
     }
@@ -1144,6 +1210,72 @@ int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t
     }
     pt->camera_samples += px * samples;
   }
+  return SRT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int srt_pt_render_epoch_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples,
+                               float* d_tiles_out) {
+  if (!d_tiles_out) return srt::fail(SRT_ERR_INVALID, "srt_pt_render_epoch_device: output is NULL");
+  return render_device(pt, "srt_pt_render_epoch_device", stream, seed, sample_base, samples, d_tiles_out);
+}
+
+// ---- launches decoupled from the reference's epochs -------------------------------------------------------------------
+int srt_pt_max_samples_per_launch(srt_pt* pt, uint32_t* samples) {
+  if (!pt || !samples) return srt::fail(SRT_ERR_INVALID, "srt_pt_max_samples_per_launch: NULL argument");
+  if (!pt->w) return srt::fail(SRT_ERR_STATE, "srt_pt_max_samples_per_launch before srt_pt_set_params");
+  *samples = samples_per_launch(pt->tiles.local_tiles * pt->tiles.tile_w * pt->tiles.tile_h);
+  return SRT_OK;
+}
+
+int srt_pt_accumulator_floats(srt_pt* pt, size_t* nfloats) {
+  if (!pt || !nfloats) return srt::fail(SRT_ERR_INVALID, "srt_pt_accumulator_floats: NULL argument");
+  if (!pt->w) return srt::fail(SRT_ERR_STATE, "srt_pt_accumulator_floats before srt_pt_set_params");
+  const size_t px = (size_t)pt->tiles.local_tiles * pt->tiles.tile_w * pt->tiles.tile_h;
+  *nfloats = 8 * (px ? px : 1);
+  return SRT_OK;
+}
+
+int srt_pt_render_samples_device(srt_pt* pt, void* stream, uint64_t seed, uint32_t sample_base, uint32_t samples) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_render_samples_device: NULL context");
+  if (pt->kernel_mode == 1) return srt::fail(SRT_ERR_UNSUPPORTED, "srt_pt_render_samples_device: the lane-per-pixel kernel (mode 1) keeps no per-sample radiance");
+  if (pt->w) {
+    const uint32_t most = samples_per_launch(pt->tiles.local_tiles * pt->tiles.tile_w * pt->tiles.tile_h);
+    if (samples == 0 || samples > most) return srt::fail(SRT_ERR_INVALID, "srt_pt_render_samples_device: 1..%u samples per launch (got %u)", most, samples);
+  }
+  return render_device(pt, "srt_pt_render_samples_device", stream, seed, sample_base, samples, nullptr);
+}
+
+int srt_pt_fold_epochs_device(srt_pt* pt, void* stream, uint32_t samples_per_epoch, uint32_t position, uint32_t total_samples,
+                              uint32_t accumulator_samples, float* d_accumulator) {
+  int st = need_ready(pt, "srt_pt_fold_epochs_device");
+  if (st != SRT_OK) return st;
+  if (!d_accumulator || !samples_per_epoch) return srt::fail(SRT_ERR_INVALID, "srt_pt_fold_epochs_device: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  auto it = pt->epoch_buffers.find(s);
+  const uint32_t px = pt->tiles.local_tiles * pt->tiles.tile_w * pt->tiles.tile_h;
+  if (!px) return SRT_OK;                               // this rank owns no tile
+  if (it == pt->epoch_buffers.end() || !it->second.d_samples || it->second.last_npix != px || !it->second.last_samples)
+    return srt::fail(SRT_ERR_STATE, "srt_pt_fold_epochs_device: no launch of srt_pt_render_samples_device on this stream to fold");
+  const srt_pt::EpochBuffers& B = it->second;
+  if ((uint64_t)position + B.last_samples > total_samples)
+    return srt::fail(SRT_ERR_INVALID, "srt_pt_fold_epochs_device: samples %u + %u exceed the render's %u", position, B.last_samples, total_samples);
+  pt_fold_kernel<<<dim3((px + 255) / 256), dim3(256), 0, s>>>(pt->tiles, pt->w, pt->h, B.last_samples, B.d_samples, samples_per_epoch, position, total_samples,
+                                                              accumulator_samples, d_accumulator, B.d_cancel);
+  SRT_HIP(hipGetLastError());
+  return SRT_OK;
+}
+
+int srt_pt_accumulator_tiles_device(srt_pt* pt, void* stream, const float* d_accumulator, float* d_tiles_out) {
+  int st = need_ready(pt, "srt_pt_accumulator_tiles_device");
+  if (st != SRT_OK) return st;
+  if (!d_accumulator || !d_tiles_out) return srt::fail(SRT_ERR_INVALID, "srt_pt_accumulator_tiles_device: NULL buffer");
+  const uint32_t px = pt->tiles.local_tiles * pt->tiles.tile_w * pt->tiles.tile_h;
+  if (!px) return SRT_OK;
+  pt_acc_image_kernel<<<dim3((px + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(pt->tiles, d_accumulator, d_tiles_out);
+  SRT_HIP(hipGetLastError());
   return SRT_OK;
 }
 
@@ -1185,10 +1317,11 @@ int srt_pt_render_epoch(srt_pt* pt, uint64_t seed, uint32_t sample_base, uint32_
   }
   st = srt_pt_render_epoch_device(pt, (void*)pt->stream, seed, sample_base, samples, pt->d_tile_buf);
   if (st != SRT_OK) return st;
-  std::vector<float> host(per_tile * T.local_tiles);
-  if (!host.empty()) SRT_HIP(hipMemcpyAsync(host.data(), pt->d_tile_buf, host.size() * sizeof(float), hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
+  if (__atomic_load_n(pt->h_cancel, __ATOMIC_ACQUIRE) != 0u) return SRT_CANCELLED;   // the epoch was cut short: rgb_out is not written
   if ((st = check_stream_fault(pt, "srt_pt_render_epoch")) != SRT_OK) return st;
+  std::vector<float> host(per_tile * T.local_tiles);
+  if (!host.empty()) SRT_HIP(hipMemcpy(host.data(), pt->d_tile_buf, host.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (uint32_t k = 0; k < T.local_tiles; k++) {
     const uint32_t tile = T.rank + k * T.world;
     const uint32_t x0 = (tile % T.tiles_x) * T.tile_w, y0 = (tile / T.tiles_x) * T.tile_h;
@@ -1273,7 +1406,7 @@ int srt_pt_stream_counters(srt_pt* pt, uint64_t out[4], int reset) {
   //   per queued entry: origin + direction planes (2 x 16 B) and the list entry (4 B) written and read once each, the hit (8 B) written and read
   out[2] = (28u + 28u + 15u + 1u + 1u) * 4u;
   out[3] = (32u + 4u + 8u) * 2u;
-  if (reset) SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 2, 0, sizeof h));
+  if (reset) { SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 2, 0, sizeof h)); SRT_HIP(hipDeviceSynchronize()); }
   return SRT_OK;
 }
 
@@ -1296,6 +1429,7 @@ int srt_pt_ray_count(srt_pt* pt, uint64_t* rays, uint64_t* camera_samples, int r
   if (camera_samples) *camera_samples = pt->camera_samples;
   if (reset) {
     SRT_HIP(hipMemset(pt->d_totals + C_COUNT, 0, sizeof r));
+    SRT_HIP(hipDeviceSynchronize());                     // (null-stream memset: done before the next epoch's atomics on another stream)
     pt->camera_samples = 0;
   }
   return SRT_OK;
@@ -1315,7 +1449,7 @@ int srt_pt_rays_elided(srt_pt* pt, uint64_t* elided, int reset) {
   unsigned long long r = 0;
   SRT_HIP(hipMemcpy(&r, pt->d_totals + C_COUNT + 1, sizeof r, hipMemcpyDeviceToHost));
   if (elided) *elided = r;
-  if (reset) SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 1, 0, sizeof r));
+  if (reset) { SRT_HIP(hipMemset(pt->d_totals + C_COUNT + 1, 0, sizeof r)); SRT_HIP(hipDeviceSynchronize()); }
   return SRT_OK;
 }
 
@@ -1569,6 +1703,109 @@ int srt_pt_math_div_sqrt(srt_pt* pt, const float* in, size_t lanes, int shared_c
   SRT_HIP(hipMemcpyAsync(out, dout, 4 * n3 * 4, hipMemcpyDeviceToHost, pt->stream));
   SRT_HIP(hipStreamSynchronize(pt->stream));
   return SRT_OK;
+}
+
+
+// ---- Pathtracer::cancel ---------------------------------------------------------------------------------------------
+int srt_pt_cancel(srt_pt* pt) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_cancel: NULL context");
+  if (pt->h_cancel) __atomic_store_n(pt->h_cancel, 1u, __ATOMIC_RELEASE);   // (no HIP call: any thread, any time)
+  return SRT_OK;
+}
+
+int srt_pt_cancel_requested(srt_pt* pt) {
+  return pt && pt->h_cancel && __atomic_load_n(pt->h_cancel, __ATOMIC_ACQUIRE) != 0u ? 1 : 0;
+}
+
+int srt_pt_clear_cancel(srt_pt* pt) {
+  int st = need_device(pt, "srt_pt_clear_cancel");
+  if (st != SRT_OK) return st;
+  SRT_HIP(hipDeviceSynchronize());                       // what was in flight has drained (it ends early once the flag is seen)
+  __atomic_store_n(pt->h_cancel, 0u, __ATOMIC_RELEASE);
+  for (auto& kv : pt->epoch_buffers)
+    if (kv.second.d_cancel) SRT_HIP(hipMemset(kv.second.d_cancel, 0, sizeof(uint32_t)));
+  SRT_HIP(hipDeviceSynchronize());                       // (the memsets are on the null stream: done before any stream's next kernel)
+  *(volatile uint32_t*)pt->h_fault = 0u;                 // (a cancelled streamed launch leaves no fault, but nothing stale either)
+  return SRT_OK;
+}
+
+// ---- Pathtracer::log_ray --------------------------------------------------------------------------------------------
+int srt_pt_set_ray_log(srt_pt* pt, uint32_t capacity) {
+  if (!pt) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_ray_log: NULL context");
+  if (capacity > (1u << 26)) return srt::fail(SRT_ERR_INVALID, "srt_pt_set_ray_log: at most 2^26 rays per read (got %u)", capacity);
+  pt->ray_log_cap = capacity;                            // the rings follow at the next epoch on each stream (stream_buffers)
+  return SRT_OK;
+}
+
+namespace {
+// `rays` == nullptr: only count what is waiting in the ring (nothing is consumed).
+int read_ring(srt_pt::EpochBuffers& B, hipStream_t s, std::vector<srt_pt_logged_ray>* rays, size_t* waiting, uint64_t* dropped) {
+  if (!B.d_ray_log) return SRT_OK;
+  uint32_t count = 0;
+  SRT_HIP(hipMemcpyAsync(&count, B.d_ray_log, sizeof count, hipMemcpyDeviceToHost, s));
+  SRT_HIP(hipStreamSynchronize(s));
+  const uint32_t n = count < B.ray_log_cap ? count : B.ray_log_cap;
+  if (waiting) *waiting += n;
+  if (!rays) return SRT_OK;
+  if (dropped) *dropped += count - n;
+  if (!count) return SRT_OK;
+  std::vector<uint32_t> raw((size_t)kRayLogWords * n);
+  if (n) SRT_HIP(hipMemcpyAsync(raw.data(), B.d_ray_log + kRayLogHeader, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  SRT_HIP(hipMemsetAsync(B.d_ray_log, 0, sizeof(uint32_t), s));
+  SRT_HIP(hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t* e = &raw[(size_t)kRayLogWords * i];
+    srt_pt_logged_ray r;
+    std::memcpy(r.point, e, 12); std::memcpy(r.dir, e + 3, 12);
+    r.t = 5.0f;                                          // log_ray(world_ray_task6, 5.0f), student/pathtracer.cpp:148
+    r.pixel = e[6]; r.sample = e[7] >> 4; r.bounce = e[7] & 15u;
+    rays->push_back(r);
+  }
+  return SRT_OK;
+}
+int deliver_rays(std::vector<srt_pt_logged_ray>& rays, srt_pt_logged_ray* out, size_t cap, size_t* n_out, uint64_t* dropped) {
+  // the order a single-threaded do_trace would log them in: pixel-major, then sample, then bounce
+  std::sort(rays.begin(), rays.end(), [](const srt_pt_logged_ray& a, const srt_pt_logged_ray& b) {
+    if (a.pixel != b.pixel) return a.pixel < b.pixel;
+    if (a.sample != b.sample) return a.sample < b.sample;
+    return a.bounce < b.bounce;
+  });
+  const size_t n = rays.size() < cap ? rays.size() : cap;
+  if (n) std::memcpy(out, rays.data(), n * sizeof(srt_pt_logged_ray));
+  if (dropped) *dropped += rays.size() - n;              // (what the caller's buffer did not take is gone as well)
+  if (n_out) *n_out = n;
+  return SRT_OK;
+}
+int read_log(srt_pt* pt, bool all_streams, hipStream_t s, srt_pt_logged_ray* out, size_t cap, size_t* n_out, uint64_t* dropped) {
+  if (dropped) *dropped = 0;
+  if (n_out) *n_out = 0;
+  int st;
+  if (!out) {                                            // how many are waiting
+    size_t waiting = 0;
+    if (all_streams) SRT_HIP(hipDeviceSynchronize());
+    for (auto& kv : pt->epoch_buffers)
+      if ((all_streams || kv.first == s) && (st = read_ring(kv.second, kv.first, nullptr, &waiting, nullptr)) != SRT_OK) return st;
+    if (n_out) *n_out = waiting;
+    return SRT_OK;
+  }
+  std::vector<srt_pt_logged_ray> rays;
+  if (all_streams) SRT_HIP(hipDeviceSynchronize());
+  for (auto& kv : pt->epoch_buffers)
+    if ((all_streams || kv.first == s) && (st = read_ring(kv.second, kv.first, &rays, nullptr, dropped)) != SRT_OK) return st;
+  return deliver_rays(rays, out, cap, n_out, dropped);
+}
+}  // namespace
+
+int srt_pt_read_ray_log_stream(srt_pt* pt, void* stream, srt_pt_logged_ray* out, size_t cap, size_t* n_out, uint64_t* dropped) {
+  int st = need_device(pt, "srt_pt_read_ray_log_stream");
+  if (st != SRT_OK) return st;
+  return read_log(pt, false, (hipStream_t)stream, out, cap, n_out, dropped);
+}
+
+int srt_pt_read_ray_log(srt_pt* pt, srt_pt_logged_ray* out, size_t cap, size_t* n_out, uint64_t* dropped) {
+  int st = need_device(pt, "srt_pt_read_ray_log");
+  if (st != SRT_OK) return st;
+  return read_log(pt, true, nullptr, out, cap, n_out, dropped);
 }
 
 int srt_pt_sync(srt_pt* pt) {

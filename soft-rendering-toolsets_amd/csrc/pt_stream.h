@@ -136,6 +136,7 @@ struct CastParams {
   uint32_t pops;             // pops a lane may take per walk trip (1 or 2)
   uint32_t obj_shift;
   unsigned long long* stats;   // STATS build only: CS_* sums over all waves
+  const uint32_t* dev_cancel;  // srt_pt_cancel reached the device (pt_wave.h): nothing is cast
 };
 
 // Dense list of the queue positions that carry a ray: the logic kernel left one mask word per path slot (bit q: queue slot
@@ -145,8 +146,15 @@ constexpr uint32_t kCompactChunk = 8192;
 // streamed forms' ray-state traffic with (srt_pt_stream_counters).
 __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __restrict__ emit, uint32_t nlanes, uint32_t nslots,
                                                           StreamCounters* sc, uint32_t gen, uint32_t* __restrict__ ray_id,
-                                                          unsigned long long* __restrict__ totals) {
+                                                          unsigned long long* __restrict__ totals, const uint32_t* host_cancel, uint32_t* dev_cancel) {
   if (sc->done != 0u) return;
+  // srt_pt_cancel: this kernel's first thread looks at the host's flag once per generation (one read over PCIe); a raised flag ends
+  // the launch like its last generation does - `done` - and stays in dev_cancel for the launches of the epoch still to come
+  if (__hip_atomic_load(dev_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  if (blockIdx.x == 0u && threadIdx.x == 0u && __hip_atomic_load(host_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+    atomicExch(dev_cancel, 1u);
+    sc->done = 1u;
+  }
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_live[16];
   __shared__ uint32_t s_base;
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __rest
 // too small (a batch type the bound does not know), units are unfinished and their samples stale: `fault` (host-visible, sticky)
 // is raised and the next synchronising call of the C ABI fails instead of handing out a wrong image.
 __global__ void pt_stream_finish_kernel(unsigned long long* __restrict__ block_counters, uint32_t nblocks, unsigned long long* __restrict__ totals,
-                                        const StreamCounters* __restrict__ sc, uint32_t* __restrict__ fault) {
-  if (threadIdx.x == 0 && sc->done == 0u) atomicOr(fault, 1u);
+                                        const StreamCounters* __restrict__ sc, uint32_t* __restrict__ fault, const uint32_t* dev_cancel) {
+  if (threadIdx.x == 0 && sc->done == 0u && *dev_cancel == 0u) atomicOr(fault, 1u);   // (a cancelled launch is cut short on purpose)
   unsigned long long a = 0, b = 0;
   for (uint32_t i = threadIdx.x; i < nblocks; i += blockDim.x) {
     a += block_counters[2 * (size_t)i]; b += block_counters[2 * (size_t)i + 1];
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
 #if SRT_CAST_LEAF_SPREAD
   __shared__ uint8_t cast_pairs[4 * 64];                  // leaf phase: owner lane | place in the leaf << 6 of each (ray, triangle) pair, per wave
 #endif
+  if (P.sc->done != 0u || __hip_atomic_load(P.dev_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   const uint32_t nrays = *P.nrays;
   if (nrays == 0u) {
     // nothing to cast.  If no slot is alive either and the unit queue is drained, the launch is finished.

@@ -36,7 +36,26 @@ struct DScene {
   Camera cam;
   uint32_t w, h, max_depth;
   uint32_t elide;                  // srt_pt_set_elision and the proof holds for this scene: the dead direct ray is not traced
+  // Pathtracer::log_ray (rays/pathtracer.cpp:191-193): ring of the rays the 0.0005 coin of sample_direct_lighting selects
+  // (student/pathtracer.cpp:148); word 0 = rays logged so far (may exceed the capacity: the surplus is dropped), entries of
+  // kRayLogWords words from word kRayLogHeader on.  NULL: nothing is logged (the coin is drawn all the same).
+  uint32_t* ray_log;
+  uint32_t ray_log_cap;
 };
+
+constexpr uint32_t kRayLogHeader = 8, kRayLogWords = 8;
+// One logged ray: {point, dir (normalised, as Ray's constructor leaves it), pixel = y * w + x, sample << 4 | bounce}.  `key` is the
+// RNG stream constant of the sample, ((pixel << 32 | sample) << 1) | 1 (Rng::key): every kernel form carries it.
+SRT_DEV void log_ray_event(uint32_t* ring, uint32_t cap, float px, float py, float pz, float dx, float dy, float dz, uint64_t key, uint32_t bounce) {
+  const uint32_t i = atomicAdd(ring, 1u);
+  if (i < cap) {
+    uint32_t* e = ring + kRayLogHeader + (size_t)kRayLogWords * i;
+    e[0] = __float_as_uint(px); e[1] = __float_as_uint(py); e[2] = __float_as_uint(pz);
+    e[3] = __float_as_uint(dx); e[4] = __float_as_uint(dy); e[5] = __float_as_uint(dz);
+    e[6] = (uint32_t)(key >> 33);
+    e[7] = ((uint32_t)(key >> 1) << 4) | (bounce & 15u);
+  }
+}
 
 // Image-tile shard of one rank: tiles t with t % world == rank, numbered row-major.
 struct TileMap { uint32_t tile_w, tile_h, tiles_x, tiles_y, rank, world, local_tiles; };
@@ -730,7 +749,8 @@ SRT_DEV Spec path_sample(const DScene& S, uint32_t x, uint32_t y, Rng& rng, Coun
       const V3 to_light = light_sample(S, sf.position, rng);
       const V3 chosen = rng.coin(0.5f) ? world_in : to_light;
       const Ray r6 = make_ray(sf.position, chosen, kEps, FLT_MAX);
-      (void)rng.coin(0.0005f);  // the ray-log coin is always flipped (student/pathtracer.cpp:148)
+      // the ray-log coin is always flipped (student/pathtracer.cpp:148); when it fires the ray goes to the GUI's log
+      if (rng.coin(0.0005f) && S.ray_log) log_ray_event(S.ray_log, S.ray_log_cap, r6.o.x, r6.o.y, r6.o.z, r6.d.x, r6.d.y, r6.d.z, rng.inc, (uint32_t)level);
       Spec d6 = emitted_along<COUNT>(S, r6, cnt);
       const float pdf_area = light_pdf<COUNT>(S, sf.position, to_light, cnt);
       const float pdf4 = lambert_pdf(out_dir);

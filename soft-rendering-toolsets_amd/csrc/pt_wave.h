@@ -81,7 +81,17 @@ struct WaveParams {
   unsigned long long* block_counters;   // [block][2]: rays counted / rays elided by that block of the logic kernel, all generations
   uint32_t gen;              // generation number
   uint32_t obj_shift;        // packed hit = object slot << obj_shift | triangle
+  // srt_pt_cancel (Pathtracer::cancel, rays/pathtracer.cpp:282-290 - the reference tests cancel_flag after every sample, :224):
+  // host_cancel is the context's flag in pinned, device-visible host memory; dev_cancel the stream's sticky copy in device
+  // memory, which every wave of every kernel of the epoch reads once, at its start.  ONE wave of a persistent launch looks at the
+  // host word whenever it fetches work, and on seeing it set raises dev_cancel and moves the unit queue's head past its end:
+  // every other wave then finds the queue drained at its next fetch - no wave pays for a read over PCIe in its loop.
+  const uint32_t* host_cancel;
+  uint32_t* dev_cancel;
 };
+constexpr unsigned long long kQueuePoison = 1ull << 62;
+SRT_DEV bool cancel_raised(const uint32_t* dev_cancel) { return __hip_atomic_load(dev_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
+SRT_DEV bool cancel_requested(const uint32_t* host_cancel) { return __hip_atomic_load(host_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u; }
 
 constexpr uint32_t kStreamBlock = 256;    // threads per block of the streamed logic kernels (one queue atomic per block; four waves, so
                                           // that a CU takes the next block as soon as four waves are done)
@@ -506,6 +516,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
   if constexpr (STREAM) {
     if (P_in.sc->done != 0u) return;                     // every unit is finished: the remaining generations are no-ops
   }
+  if (cancel_raised(P_in.dev_cancel)) return;            // srt_pt_cancel: what is left of the epoch is not rendered
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
@@ -729,7 +740,13 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
           if (queue_empty) break;
           unsigned long long start = 0;
           const uint32_t grab = P.chunk;
-          if (lane == 0) start = atomicAdd(P.queue_head, (unsigned long long)grab);
+          if (lane == 0) {
+            if (blockIdx.x == 0u && wave == 0 && cancel_requested(P.host_cancel)) {      // (this wave looks for the others)
+              atomicExch(P.dev_cancel, 1u);
+              atomicMax(P.queue_head, kQueuePoison);
+            }
+            start = atomicAdd(P.queue_head, (unsigned long long)grab);
+          }
           start = __shfl(start, 0);
           if (start >= P.total_units) { queue_empty = true; break; }
           chunk_next = (uint32_t)start;
@@ -1283,7 +1300,11 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
         if (!discrete) {
           const V3 to_light = light_sample(S, sf.position, rng);
           chosen = rng.coin(0.5f) ? world_in : to_light;
-          (void)rng.coin(0.0005f);
+          // log_ray(world_ray_task6, 5.0f) with probability 0.0005 (student/pathtracer.cpp:148): the coin is always drawn
+          if (rng.coin(0.0005f) && S.ray_log) {
+            const V3 ld = unit(chosen);
+            log_ray_event(S.ray_log, S.ray_log_cap, sf.position.x, sf.position.y, sf.position.z, ld.x, ld.y, ld.z, rng.inc, level);
+          }
           pdf_area = light_pdf<false>(S, sf.position, to_light, cnt);
         }
         if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
@@ -1349,7 +1370,8 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
 // Adds the samples of each pixel in sample order with do_trace's validity filter.  A render of more than one
 // launch carries (sum, count) in `running` (4 floats per pixel slot); the last launch scales by 1/count.
 __global__ void pt_reduce_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t samples, const float* __restrict__ sample_out,
-                                 float* __restrict__ running, int first, int last, float* __restrict__ tiles_out) {
+                                 float* __restrict__ running, int first, int last, float* __restrict__ tiles_out, const uint32_t* dev_cancel) {
+  if (*dev_cancel != 0u) return;                         // srt_pt_cancel: the launch was cut short, its samples are not an epoch
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= T.local_tiles * T.tile_w * T.tile_h) return;
   uint32_t x, y;
@@ -1374,6 +1396,54 @@ __global__ void pt_reduce_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t sam
     running[4 * (size_t)p] = acc.r; running[4 * (size_t)p + 1] = acc.g; running[4 * (size_t)p + 2] = acc.b;
     running[4 * (size_t)p + 3] = __uint_as_float(sampled);
   }
+}
+
+
+// Pathtracer::do_trace's per-pixel epoch mean AND Pathtracer::accumulate's running mean (rays/pathtracer.cpp:195-231) for the samples
+// of ONE launch, epoch by epoch, straight from the per-sample buffer: the device renders launches of up to 64 samples per pixel
+// whatever the reference's epoch size is (samples_per_epoch = max(1, n / (hw_threads * 10)), often 1), and this kernel restores
+// the reference's bookkeeping - sample j of the render belongs to epoch j / spe; an epoch's mean is the sum of its valid samples
+// in order times 1 / count (a zero Spectrum when none is valid); the accumulator takes s += (mean - s) * (1.0f / k) with k the
+// epoch's 1-based number.  State per pixel slot p (8 floats): {acc rgb, -, sum rgb, count}: the epoch in progress is carried from
+// one launch of the render to the next.  pos = samples of the render in front of this launch, total = samples of the whole render
+// (its last epoch may be short), first_k = epochs the accumulator held before the render.
+__global__ void pt_fold_kernel(TileMap T, uint32_t w, uint32_t h, uint32_t samples, const float* __restrict__ sample_out, uint32_t spe,
+                               uint32_t pos, uint32_t total, uint32_t first_k, float* __restrict__ state, const uint32_t* dev_cancel) {
+  if (*dev_cancel != 0u) return;                         // the launch was cut short (srt_pt_cancel): nothing of it is folded
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t npix = T.local_tiles * T.tile_w * T.tile_h;
+  if (p >= npix) return;
+  uint32_t x, y;
+  unit_pixel(T, p, x, y);
+  if (x >= w || y >= h) return;                          // padding pixels of edge tiles stay zero
+  float4* st = reinterpret_cast<float4*>(state) + 2 * (size_t)p;
+  float4 a = st[0], c = st[1];
+  Spec acc = spec(a.x, a.y, a.z), sum = spec(c.x, c.y, c.z);
+  uint32_t cnt = __float_as_uint(c.w);
+  const float4* src = reinterpret_cast<const float4*>(sample_out) + p;   // [sample][pixel slot]
+  for (uint32_t s = 0; s < samples; s++) {
+    const float4 q = src[(size_t)s * npix];
+    const Spec v = spec(q.x, q.y, q.z);
+    if (valid(v)) { sum = sum + v; cnt++; }
+    const uint32_t idx = pos + s + 1u;
+    if (idx % spe == 0u || idx == total) {
+      if (cnt > 0u) sum = sum * (1.0f / cnt);
+      const uint32_t k = first_k + (idx + spe - 1u) / spe;
+      acc = acc + (sum - acc) * (1.0f / k);
+      sum = spec(0, 0, 0); cnt = 0u;
+    }
+  }
+  st[0] = make_float4(acc.r, acc.g, acc.b, 0.0f);
+  st[1] = make_float4(sum.r, sum.g, sum.b, __uint_as_float(cnt));
+}
+
+// The accumulator of this rank's pixels as tile radiance (the layout srt_pt_render_epoch_device writes and the gather moves).
+__global__ void pt_acc_image_kernel(TileMap T, const float* __restrict__ state, float* __restrict__ tiles_out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= T.local_tiles * T.tile_w * T.tile_h) return;
+  const float4 a = reinterpret_cast<const float4*>(state)[2 * (size_t)p];
+  float* out = tiles_out + (size_t)tile_slot(T, p) * 3;
+  out[0] = a.x; out[1] = a.y; out[2] = a.z;
 }
 
 }  // namespace srt

@@ -1234,6 +1234,10 @@ int srt_raster_create(int device, srt_raster** out) {
     return srt::fail(SRT_ERR_HIP, "hipMalloc(stats) failed");
   }
   std::memset(r->h_status, 0, FS_COUNT * sizeof(uint32_t));
+  // hipMemset is ordered on the NULL stream; the context's kernels run on a non-blocking stream that does not wait for it.  Without
+  // this wait the first frame could read what the allocation held before (seen on a box whose memory had been used: a stale
+  // "line cannot be walked" flag refused a stream without lines).
+  (void)hipDeviceSynchronize();
   if (hipEventCreateWithFlags(&r->upload_done, hipEventDisableTiming) != hipSuccess) {
     (void)hipFree(r->d_stats); (void)hipFree(r->d_status); (void)hipHostFree(r->h_status);
     (void)hipStreamDestroy(r->stream);

@@ -3,6 +3,7 @@
 #include "pathtracer_hip.h"
 
 #include <cstring>
+#include <limits>
 
 #include "camera_iview.h"
 
@@ -35,7 +36,22 @@ static void fatal(const char* what, int status, const char* message) {
     die("%s failed (%d): %s", what, status, message);
 }
 
+// Pathtracer::log_ray (rays/pathtracer.cpp:191-193): the rays sample_direct_lighting's 0.0005 coin selected
+// (student/pathtracer.cpp:148: log_ray(world_ray_task6, 5.0f), color = Spectrum{1.0f}), recorded by the kernels and replayed
+// into the GUI's ray log after every launch, on the render thread (Widget_Render::log_ray takes its own mutex, gui/widgets.cpp:625-628).
+void Pathtracer::deliver_logged_rays(void* self, const srt_pt_logged_ray* rays, size_t n) {
+    Pathtracer* pt = static_cast<Pathtracer*>(self);
+    for(size_t i = 0; i < n; i++) {
+        Ray ray;                                           // (the direction is already the unit vector Ray's constructor makes)
+        ray.point = Vec3(rays[i].point[0], rays[i].point[1], rays[i].point[2]);
+        ray.dir = Vec3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        ray.dist_bounds = Vec2(EPS_F, std::numeric_limits<float>::max());
+        pt->gui.log_ray(ray, rays[i].t, Spectrum(1.0f));
+    }
+}
+
 Pathtracer::Pathtracer(Gui::Widget_Render& gui, Vec2) : gui(gui), core(nullptr, 0, fatal) {
+    core.set_ray_log(&Pathtracer::deliver_logged_rays, this);
 }
 
 Pathtracer::~Pathtracer() {

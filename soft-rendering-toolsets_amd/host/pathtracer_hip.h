@@ -3,7 +3,8 @@
 // include/srt_pt.h.  The PUBLIC surface is the reference's, signature for signature (pathtracer.h:24-40), so
 // Gui::Widget_Render (gui/widgets.h:131, gui/widgets.cpp:788-968) compiles and behaves unchanged:
 // begin_render is asynchronous, progress()/in_progress() are polled, get_output()/get_output_texture() hand out
-// the running-mean accumulator, cancel() stops between epochs, "Add Samples" keeps the accumulator.
+// the running-mean accumulator, cancel() stops the launches in flight within milliseconds (srt_pt_cancel), "Add Samples"
+// keeps the accumulator, and the rays log_ray's coin selects reach gui.log_ray.
 //
 // To integrate: build this header/implementation INSTEAD of rays/pathtracer.{h,cpp} and student/pathtracer.cpp
 // (INTEGRATION.md).  There is no CPU path behind it: without a HIP device the constructor dies like the
@@ -63,6 +64,7 @@ public:
     void set_seed(unsigned long long s) { core.set_seed(s); }
 
 private:
+    static void deliver_logged_rays(void* self, const srt_pt_logged_ray* rays, size_t n);   // Pathtracer::log_ray -> gui.log_ray
     void build_scene(Scene& scene);              // rays/pathtracer.cpp:66-176 -> srt_pt_scene_* on every device's context
     void feed_scene(srt_pt* ctx, Scene& scene);  // the object / light / particle walk for one context
 

@@ -34,6 +34,8 @@ CASES = [
     ("cfg3_cbox_lambertian_512_64spp", "cbox_lambertian", 512, 512, 8, 64, 0, 0),        # BASELINE configs[2], whole
     ("cfg4_cbox_1024_4spp", "cbox", 1024, 1024, 8, 4, 0, 0),                             # configs[3] at 4 of its 2048 spp
     ("cfg4_cbox_1024_3spp_base61", "cbox", 1024, 1024, 8, 3, 0, 61),                     # ... an odd count at a later sample index
+    ("cfg4_cbox_1024_64spp", "cbox", 1024, 1024, 8, 64, 0, 0),                           # one whole step of bench.py (64 spp): the image every
+                                                                                         # `bench.py --gpus N` / `--group N` run must reproduce
     ("cfg5_blob131072_1024_2spp", "cbox_blob131072_glass", 1024, 1024, 8, 2, 0, 0),      # configs[4] stand-in mesh
     ("cfg5_beast_1024_2spp", "cbox_beast_glass", 1024, 1024, 8, 2, 0, 0),                # configs[4] with the reference's largest asset
 ]

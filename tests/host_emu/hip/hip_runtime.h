@@ -15,4 +15,5 @@ static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned long long __ballot(int pred) { return pred ? 1ull : 0ull; }   // a "wave" of one lane
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p = old + v; return old; }   // one lane: no race
 #endif

@@ -43,4 +43,14 @@ void core_tonemap(void* h, unsigned char* out, float exposure) {
   std::memcpy(out, v.data(), v.size());
 }
 
+// Pathtracer::log_ray's sink: the driver keeps what the core delivers (40 bytes per ray, srt_pt_logged_ray) for the test to fetch
+static std::vector<srt_pt_logged_ray> g_logged;
+static void keep_rays(void*, const srt_pt_logged_ray* rays, size_t n) { g_logged.insert(g_logged.end(), rays, rays + n); }
+void core_enable_ray_log(void* h, unsigned capacity) { g_logged.clear(); ((srt_host::RenderCore*)h)->set_ray_log(keep_rays, nullptr, capacity); }
+size_t core_logged_rays(void* out, size_t cap) {
+  const size_t n = g_logged.size() < cap ? g_logged.size() : cap;
+  if (out && n) std::memcpy(out, g_logged.data(), n * sizeof(srt_pt_logged_ray));
+  return g_logged.size();
+}
+
 }  // extern "C"

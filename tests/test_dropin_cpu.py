@@ -1,5 +1,5 @@
 """CPU: the drop-in PT::Pathtracer's camera matrix.  The class reads Camera::iview - private, no getter - through the
-explicit-instantiation accessor of soft-rendering-toolsets_amd/host/camera_iview.h; oracle/_ref/libdropin_pt.so (that header
+explicit-instantiation accessor of soft-rendering-toolsets_amd/host/camera_iview.h; integration/_build/libdropin_pt.so (that header
 + the reference's util/camera.cpp, authoring container) lets the test compare it with the member itself."""
 import ctypes
 import os
@@ -9,10 +9,10 @@ import pytest
 
 import _harness as H
 
-LIB = os.path.join(H.ORACLE_DIR, "_ref", "libdropin_pt.so")
+LIB = os.path.join(H.ROOT, "integration", "_build", "libdropin_pt.so")
 
 
-@pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libdropin_pt.so is built in the authoring container (make -C oracle ref)")
+@pytest.mark.skipif(not os.path.exists(LIB), reason="integration/_build/libdropin_pt.so is built in the authoring container (make -C integration)")
 def test_camera_iview_accessor_is_the_private_matrix():
     lib = ctypes.CDLL(LIB)
     rng = np.random.default_rng(5)
@@ -51,10 +51,10 @@ def test_lookat_pose_of_the_cornell_camera_matches_the_reference_builder():
 
 
 def test_full_class_harness_scene_dump_is_a_scene_the_oracle_takes():
-    """oracle/_ref/libdropin_pt_full.so (the whole PT::Pathtracer class inside the reference's scene layer; the render itself is a GPU
+    """integration/_build/libdropin_pt_full.so (the whole PT::Pathtracer class inside the reference's scene layer; the render itself is a GPU
     test): its dump-only mode - Scene_Object / Scene_Light / Scene_Particles instances read the way the reference's build_scene reads
     them - parses into a scene description that the oracle commits and renders: the counts of each kind are what
-    ref_harness/pt_full.cpp builds, and an epoch of it is finite and lit."""
+    integration/harness/pt_full.cpp builds, and an epoch of it is finite and lit."""
     import ctypes
     import importlib.util
     import os
@@ -63,9 +63,9 @@ def test_full_class_harness_scene_dump_is_a_scene_the_oracle_takes():
 
     import _harness as H
 
-    path = os.path.join(H.ORACLE_DIR, "_ref", "libdropin_pt_full.so")
+    path = os.path.join(H.ROOT, "integration", "_build", "libdropin_pt_full.so")
     if not os.path.exists(path) or not os.path.exists(os.path.join(H.ROOT, "soft-rendering-toolsets_amd", "lib", "libsrt_hip.so")):
-        pytest.skip("oracle/_ref/libdropin_pt_full.so is built in the authoring container (make -C oracle ref)")
+        pytest.skip("integration/_build/libdropin_pt_full.so is built in the authoring container (make -C integration)")
     spec = importlib.util.spec_from_file_location("_tdg", os.path.join(H.ROOT, "tests", "test_dropin_gpu.py"))
     tdg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tdg)

@@ -57,6 +57,31 @@ def test_oracle_matches_reference_golden(path, math_mode):
         assert bits_equal(o2.epoch(seed, base, spp), g["epoch"]), "epoch image differs from the reference"
 
 
+LOG_GOLDENS = sorted(glob.glob(os.path.join(H.GOLDEN, "ptlog_*.npz")))
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "srtmath"])
+@pytest.mark.parametrize("path", LOG_GOLDENS, ids=[os.path.basename(g)[6:-4] for g in LOG_GOLDENS])
+def test_oracle_ray_log_matches_reference_golden(path, math_mode):
+    """Pathtracer::log_ray: the rays the reference build handed to Gui::Widget_Render::log_ray over one epoch (arguments and call order,
+    tests/golden/make_pt_logray_golden.py) against the oracle's - and, where the reference build is present, against it again."""
+    g = np.load(path)
+    w, h, depth, use_bvh, spp, base = (int(x) for x in g["meta"])
+    scene = pt_scene(str(g["scene"]))
+    assert scene_digest(scene) == str(g["scene_sha256"])
+    o = H.OraclePT(scene, w, h, depth, bool(use_bvh), math_mode=math_mode)
+    img, log = o.epoch_log(int(g["seed"]), base, spp)
+    assert bits_equal(img, g["epoch"])
+    assert len(log) == len(g["pixel"]) >= 8
+    assert bits_equal(log[:, 0:3], g["point"]) and bits_equal(log[:, 3:6], g["dir"]) and bits_equal(log[:, 6], g["t"])
+    assert np.array_equal(log[:, 7].astype(np.uint32), g["pixel"]) and np.array_equal(log[:, 8].astype(np.uint32), g["sample"])
+    assert np.array_equal(log[:, 9].astype(np.uint32), g["bounce"])
+    if H.have_reference() and math_mode == 0:
+        rimg, rlog = H.RefPT(scene, w, h, depth, bool(use_bvh)).epoch_log(int(g["seed"]), base, spp)
+        assert bits_equal(rimg, img) and bits_equal(rlog[:, :9], log[:, :9])
+        assert (rlog[:, 10:13] == 1.0).all()            # color = Spectrum{1.0f}
+
+
 def test_particle_step_matches_reference_golden():
     """Scene_Particles::Particle::update (SURVEY.md 8(f)-4) as restated by the oracle against the states the reference produced
     over three steps (tests/golden/make_particles_golden.py), NaN positions of the particles at rest included; and scene.hit
