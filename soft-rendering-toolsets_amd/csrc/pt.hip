@@ -342,6 +342,7 @@ struct srt_pt {
     uint32_t* d_cast_spill = nullptr; size_t cast_spill_words = 0;   // the ray-cast kernel's traversal frames beyond those in LDS
     uint32_t* d_cancel = nullptr;                                     // srt_pt_cancel as the kernels of this stream have seen it (sticky until srt_pt_clear_cancel)
     uint32_t* d_ray_log = nullptr; uint32_t ray_log_cap = 0;          // srt_pt_set_ray_log: this stream's ring (pt_trace.h: log_ray_event)
+    uint32_t* d_alive_list = nullptr; size_t alive_list_n = 0;          // streamed forms: the alive slots the next generation works from
     uint32_t last_samples = 0, last_npix = 0;                         // what d_samples holds: samples per pixel and pixel slots of the last launch
   };
   std::map<hipStream_t, EpochBuffers> epoch_buffers;
@@ -779,6 +780,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       if ((st = ensure(&B.d_ray_d, &B.ray_d_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
       if ((st = ensure(&B.d_ray_id, &B.ray_id_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
       if ((st = ensure(&B.d_hits, &B.hits_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_alive_list, &B.alive_list_n, (size_t)nlanes)) != SRT_OK) return st;
       if (B.block_counters_n < 2 * (size_t)nblocks) {
         if ((st = ensure(&B.d_block_counters, &B.block_counters_n, 2 * (size_t)nblocks)) != SRT_OK) return st;
         SRT_HIP(hipMemsetAsync(B.d_block_counters, 0, 2 * (size_t)nblocks * sizeof(unsigned long long), s));
@@ -790,6 +792,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       P.block_counters = B.d_block_counters;
       P.obj_shift = stream_obj_shift(F);
       P.host_cancel = pt->d_host_cancel; P.dev_cancel = B.d_cancel;
+      P.alive_list = B.d_alive_list;
       SRT_HIP(hipMemsetAsync(B.d_sc, 0, sizeof(StreamCounters), s));
       SRT_HIP(hipMemsetAsync(B.d_state, 0, 2 * (size_t)nlanes * sizeof(uint32_t), s));   // the flags and emit planes: every slot idle
       // generations: list scheduling of units of <= M batches on nlanes slots
@@ -839,7 +842,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
 #undef SRT_LAUNCH_LOGIC
 #undef SRT_LAUNCH_PHASE
         if ((st = stream_time_end(pt, s, 0)) != SRT_OK || (st = stream_time_begin(pt, s, 1)) != SRT_OK) return st;
-        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id, pt->d_totals + C_COUNT + 2, pt->d_host_cancel, B.d_cancel);
+        pt_compact_kernel<<<cgrid, dim3(1024), 0, s>>>(B.d_state + (size_t)SW_EMIT * nlanes, nlanes, nslots, B.d_sc, (uint32_t)g, B.d_ray_id, pt->d_totals + C_COUNT + 2, pt->d_host_cancel, B.d_cancel, B.d_alive_list);
         if ((st = stream_time_end(pt, s, 1)) != SRT_OK || (st = stream_time_begin(pt, s, 2)) != SRT_OK) return st;
         C.nrays = &B.d_sc->nrays[g & 1]; C.head = &B.d_sc->cast_head[g & 1]; C.gen = (uint32_t)g;
         const dim3 kgrid(pt->cast_blocks), kblock(pt->cast_threads);
@@ -951,7 +954,7 @@ int srt_pt_destroy(srt_pt* pt) {
     if (pt->h_fault) (void)hipHostFree(pt->h_fault);
     if (pt->h_cancel) (void)hipHostFree(pt->h_cancel);
     for (auto& kv : pt->epoch_buffers) {
-      (void)hipFree(kv.second.d_cancel); (void)hipFree(kv.second.d_ray_log);
+      (void)hipFree(kv.second.d_cancel); (void)hipFree(kv.second.d_ray_log); (void)hipFree(kv.second.d_alive_list);
       (void)hipFree(kv.second.d_samples); (void)hipFree(kv.second.d_records); (void)hipFree(kv.second.d_running); (void)hipFree(kv.second.d_queue);
       (void)hipFree(kv.second.d_state); (void)hipFree(kv.second.d_ray_o); (void)hipFree(kv.second.d_ray_d); (void)hipFree(kv.second.d_ray_id); (void)hipFree(kv.second.d_cast_spill);
       (void)hipFree(kv.second.d_hits); (void)hipFree(kv.second.d_sc); (void)hipFree(kv.second.d_block_counters);

@@ -35,6 +35,7 @@ struct StreamCounters {
   uint32_t alive[2];               // generation g left at least one slot alive: [g & 1]
   uint32_t done;                   // set once a generation left no slot alive and the unit queue is drained
   uint32_t pad;
+  uint32_t alive_n[2];             // entries of the alive-slot list generation g works from: [g & 1] (written by generation g - 1's compaction)
 };
 
 // Words of a path slot's saved state (planes of `nlanes` words).  The DL build appends its shadow-phase state.
@@ -146,7 +147,8 @@ constexpr uint32_t kCompactChunk = 8192;
 // streamed forms' ray-state traffic with (srt_pt_stream_counters).
 __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __restrict__ emit, uint32_t nlanes, uint32_t nslots,
                                                           StreamCounters* sc, uint32_t gen, uint32_t* __restrict__ ray_id,
-                                                          unsigned long long* __restrict__ totals, const uint32_t* host_cancel, uint32_t* dev_cancel) {
+                                                          unsigned long long* __restrict__ totals, const uint32_t* host_cancel, uint32_t* dev_cancel,
+                                                          uint32_t* __restrict__ alive_list) {
   if (sc->done != 0u) return;
   // srt_pt_cancel: this kernel's first thread looks at the host's flag once per generation (one read over PCIe); a raised flag ends
   // the launch like its last generation does - `done` - and stays in dev_cancel for the launches of the epoch still to come
@@ -201,6 +203,37 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(const uint32_t* __rest
     }
   }
   (void)nslots;
+  // The slots that are still alive, in ascending order within this block's run: the next generation's logic kernels work from this
+  // list - lane i takes slot alive_list[i] - so that in the long tail of a launch (the unit queue is drained, the population thins out
+  // over the ~25 generations the longest units still need) their waves are full of live paths instead of mostly dead slots.  While
+  // every slot is alive the list is the identity.  (Thread t scans eight CONSECUTIVE slots here: ascending order keeps the logic
+  // kernels' plane accesses coalesced.)
+  __syncthreads();
+  const uint32_t base8 = first + threadIdx.x * kPer;
+  uint32_t amask = 0u;
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; k++) {
+    const uint32_t slot = base8 + k;
+    if (slot < nlanes && (emit[slot] & 0x80000000u) != 0u) amask |= 1u << k;
+  }
+  const uint32_t na = (uint32_t)__popc(amask);
+  uint32_t ia = na;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)ia, off); if ((int)lane >= off) ia += v; }
+  if (lane == 63u) s_wave[wave] = ia;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 16u; w++) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+    s_base = total ? atomicAdd(&sc->alive_n[(gen + 1u) & 1u], total) : 0u;
+  }
+  __syncthreads();
+  uint32_t aat = s_base + s_wave[wave] + ia - na;
+  while (amask) {
+    const uint32_t k = (uint32_t)__ffs((int)amask) - 1u;
+    amask &= amask - 1u;
+    alive_list[aat++] = base8 + k;
+  }
 }
 
 // After the last generation: the logic blocks' ray counts into the context's totals {rays, rays elided}.  The number of

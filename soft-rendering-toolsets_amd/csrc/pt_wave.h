@@ -88,6 +88,9 @@ struct WaveParams {
   // every other wave then finds the queue drained at its next fetch - no wave pays for a read over PCIe in its loop.
   const uint32_t* host_cancel;
   uint32_t* dev_cancel;
+  // streamed forms: the alive slots of the previous generation in ascending order (pt_compact_kernel); lane i of generation g >= 1
+  // works on slot alive_list[i], i < sc->alive_n[g & 1].  Generation 0 (every slot idle) works on slot = lane.
+  const uint32_t* alive_list;
 };
 constexpr unsigned long long kQueuePoison = 1ull << 62;
 SRT_DEV bool cancel_raised(const uint32_t* dev_cancel) { return __hip_atomic_load(dev_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
@@ -550,7 +553,20 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
   float* wl = lds_f + (COLD ? kColdWords * 256 : 0) + (size_t)wave * (Q > 0 ? Q - 1 : 0) * (2 * NR) * 64 + lane;   // (PHASE 2: no dynamic LDS, never touched)
 #define SLOT(q, r, f) wl[((((q) - 1) * NR + (r)) * 2 + (f)) * 64]
 
-  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane_phys = blockIdx.x * blockDim.x + threadIdx.x;
+  // `lane_global` indexes everything a path slot owns (state planes, records, ray / hit planes).  Persistent kernels: the lane itself.
+  // Streamed kernels: the slot this lane serves in this generation - taken from the alive list once the launch has one.
+  uint32_t lane_global = lane_phys;
+  bool has_slot = true;
+  if constexpr (STREAM) {
+    if (P.gen != 0u) {
+      const uint32_t n_alive = P.sc->alive_n[P.gen & 1u];
+      if (PHASE != 2 && lane_phys == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; P.sc->alive_n[(P.gen + 1u) & 1u] = 0u; }
+      if (blockIdx.x * blockDim.x >= n_alive) return;    // (a whole block without a live slot: nothing to do - uniform, before any barrier)
+      has_slot = lane_phys < n_alive;
+      lane_global = has_slot ? P.alive_list[lane_phys] : 0u;
+    }
+  }
   Counters cnt;
   cnt.v[C_RAYS] = 0;
   uint32_t traced = 0;                                   // rays this lane actually traced (== cnt.v[C_RAYS] when NR == 3)
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
   uint32_t emit_mask = 0;                                // queue slots of this lane that carry a ray / walk request for the next cast
   if constexpr (STREAM && PHASE == 2) {
     // the probe kernel: what the batch's rays need, nothing else
-    const uint32_t fw = ST(SW_FLAGS);
+    const uint32_t fw = has_slot ? ST(SW_FLAGS) : 0u;
     alive = (fw & 1u) != 0;
     if (alive) {
       burst = (fw & 2u) != 0; actA = (fw & 4u) != 0; actB = (fw & 8u) != 0;
@@ -628,8 +644,8 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
       if (NR > 2) d[1] = v3(__uint_as_float(ST(SW_D1)), __uint_as_float(ST(SW_D1 + 1)), __uint_as_float(ST(SW_D1 + 2)));
     }
   } else if constexpr (STREAM) {
-    if (lane_global == 0u) { P.sc->nrays[(P.gen + 1u) & 1u] = 0u; P.sc->cast_head[(P.gen + 1u) & 1u] = 0u; P.sc->alive[(P.gen + 1u) & 1u] = 0u; }   // the next generation's
-    const uint32_t fw = ST(SW_FLAGS);
+    if (P.gen == 0u && lane_phys == 0u) { P.sc->nrays[1] = 0u; P.sc->cast_head[1] = 0u; P.sc->alive[1] = 0u; P.sc->alive_n[1] = 0u; }   // the next generation's (later generations: above)
+    const uint32_t fw = has_slot ? ST(SW_FLAGS) : 0u;
     alive = (fw & 1u) != 0;
     if (alive) {
       burst = (fw & 2u) != 0; actA = (fw & 4u) != 0; actB = (fw & 8u) != 0; discrete = (fw & 16u) != 0;
@@ -663,6 +679,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
 
   bool refilled = false;                                 // PHASE 2: the slot took a new unit in this generation
   auto save_state = [&]() {
+    if (!has_slot) return;                               // (a lane past the end of the alive list serves no slot)
     if constexpr (PHASE == 2) {
       // the probe kernel changes a slot's state only by giving it a new unit: the words the refill sets (the parked hits, the RNG
       // state and the shading terms are written by the resolve kernel before anything reads them)
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
 
   for (int pass = (PHASE == 2 ? 1 : 0);; pass++) {
     // ---------------- 1. refill idle lanes ----------------
-    const unsigned long long need = (!STREAM || (PHASE != 1 && pass == 1)) ? __ballot(!alive) : 0ull;
+    const unsigned long long need = (!STREAM || (PHASE != 1 && pass == 1)) ? __ballot(!alive && has_slot) : 0ull;
     uint32_t stream_unit = kMissTri;
     if constexpr (STREAM && PHASE != 1) {
       if (pass == 1) {
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
         }
         __syncthreads();
         const unsigned long long u = s_blk[32] + s_blk[wave] + my_rank;
-        if (!alive && u < (unsigned long long)P.total_units) stream_unit = (uint32_t)u;
+        if (!alive && has_slot && u < (unsigned long long)P.total_units) stream_unit = (uint32_t)u;
         __syncthreads();                                  // (s_blk is reused below)
       }
     }

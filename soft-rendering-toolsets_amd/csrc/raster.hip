@@ -55,6 +55,7 @@ struct RasterParams {
   uint32_t super_bx, super_by;   // a super-bin is super_bx x super_by coarse bins (first binning level)
   uint32_t super_x, super_y;     // super grid (<= 8 x 8)
   uint32_t super_stride;         // entries reserved per super-bin (= nprims)
+  uint32_t packed_ok;            // a coarse bin spans <= 256 samples per side: the bin lists' packed boxes (4 x 8 bits, bin-relative) are valid
 };
 
 // Everything about one SRT_PRIM_IMAGE record that does not depend on the sample, prepared on the host at upload
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
       }
     }
     __syncthreads();
-    out = out_lists + s_base;
+    out = out_lists + 2 * (size_t)s_base;                 // (level 2 writes two words per entry: the index and the packed box)
     if (threadIdx.x == 0) offs[bin] = s_base;
     fits = s_fits != 0u;
   }
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
       uint32_t pi = 0;
       if (k < ncand) { pi = (LEVEL == 1) ? k : in[k]; bb = bbox[pi]; }
       bool ov = (bb.x <= bb.z) && (bb.x <= x1) && (bb.z >= x0) && (bb.y <= y1) && (bb.w >= y0);
+
       if (LEVEL == 2 && ov) {
         // a triangle whose box reaches into this bin but which covers none of the bin's samples is not listed: a sliver's box is
         // most of the target, its samples a thin band (the stress frame: 11.7 M (primitive, tile) pairs listed by boxes alone)
@@ -438,7 +440,17 @@ __global__ __launch_bounds__(1024) void raster_bin_pass(RasterParams P, const in
       m &= m - 1u;
       const uint32_t k = base + j * blockDim.x + threadIdx.x;
       const unsigned long long wm = s_mask[j * 16 + wave];
-      out[total + s_pref[j * 16 + wave] + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = (LEVEL == 1) ? k : in[k];
+      const uint32_t at = total + s_pref[j * 16 + wave] + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+      if (LEVEL == 1) out[at] = k;
+      else {
+        // the entry: the primitive and its box clipped to this bin, bin-relative, 4 x 8 bits (read again from L1 / L2: keeping the
+        // step's K boxes in registers cost the kernel three of its seven waves per SIMD)
+        const uint32_t pi = in[k];
+        const int4 bb = bbox[pi];
+        const uint32_t box = (uint32_t)(max(bb.x, x0) - x0) | ((uint32_t)(max(bb.y, y0) - y0) << 8) | ((uint32_t)(min(bb.z, x1) - x0) << 16) |
+                             ((uint32_t)(min(bb.w, y1) - y0) << 24);
+        reinterpret_cast<uint2*>(out)[at] = make_uint2(pi, box);
+      }
     }
     total += s_pref[NM];
     __syncthreads();                                     // (the next step rewrites the masks)
@@ -509,6 +521,17 @@ __device__ __forceinline__ float4 sample_image(const ImageAux& A, const uint8_t*
 // the fills: the 1000 slivers of the stress frame cover 11.7 M samples of 5.9 G tested, and the unrolled row loops with their
 // per-row range tests, the bookkeeping of which register holds which row and the 15-60 spilled registers cost more than the
 // 2.5 M LDS instructions of a frame.
+// WPB tiles per workgroup, one wavefront each (independent: a wave's tile, coordinates and barriers are its own).  ONE: measured in
+// round 4 with four - 65 536 tiles of a 1024^2 x 16 frame as 16 384 workgroups - BASELINE configs[1]'s tile kernel went from 90 to
+// 135 us and the stress frame from 1.29 to 1.65 ms: a workgroup keeps its LDS and wave slots until its LAST wave is done, and
+// tiles differ widely in length (bit-exact either way; -DSRT_RASTER_WPB=4 rebuilds it).
+#ifndef SRT_RASTER_WPB
+#define SRT_RASTER_WPB 1
+#endif
+constexpr int kTileWavesPerBlock = SRT_RASTER_WPB;
+// a barrier among the lanes of ONE wave: LDS operations of a wave execute in program order, so what is needed is that the
+// compiler keeps them there
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 template <bool STATS, int TSY, bool IMG>
 // (five waves per SIMD where the tile's LDS leaves room for them - 96 VGPRs, 7 spilled: 8-sample-high tiles at 20 waves per CU
 //  measure 6 % faster on cfg2 than 16-high ones at 16; six and eight waves per SIMD lose to their spills)
@@ -522,7 +545,7 @@ template <bool STATS, int TSY, bool IMG>
 //  per wave leave room; 16-high tiles stay LDS-limited at 19.  Measured: five to eight waves per SIMD all give 0.164-0.168 ms per
 //  cfg2 frame - the kernel is not short of waves.  Two tiles per wave in a loop: cfg2 0.143 -> 0.135 ms, the stress frame 6.65 -> 7.0 ms,
 //  and the loop itself cost the one-tile case 7 %: not kept.)
-__global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RASTER_OCC : SRT_RASTER_OCC_NOIMG)) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
+__global__ __launch_bounds__(WAVE * (TSY == 32 ? 1 : SRT_RASTER_WPB), TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RASTER_OCC : SRT_RASTER_OCC_NOIMG)) void raster_tiles(RasterParams P, const srt_prim* __restrict__ prims,
                                                      const int4* __restrict__ bbox,
                                                      const uint32_t* __restrict__ lists,
                                                      const uint32_t* __restrict__ counts,
@@ -534,18 +557,27 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
                                                      float4* __restrict__ samples_out,
                                                      unsigned long long* __restrict__ stats,
                                                      uint32_t* __restrict__ status, uint32_t* __restrict__ host_status) {
-  __shared__ float4 tile[TS * TSY];  // 8 / 16 KiB: the tile's slice of super_sample_buffer
+  constexpr int WPB = TSY == 32 ? 1 : kTileWavesPerBlock;
+  // per wave: the tile's slice of super_sample_buffer (4 / 8 / 16 KiB), y / sample_rate for each tile row and x / sample_rate for each
+  // tile column (fp64 divisions done once) - ONE block of LDS per wave, so that one (scalar) base serves all three
+  struct TileLds { float4 tile[TS * TSY]; double rowy[TSY]; double colx[TS]; };
+  __shared__ TileLds lds_all[WPB];
   // The frame's status words (what setup and binning needed, refusals) go to the host from here: one lane copies them into pinned
   // host memory and clears them for the next frame - a memset before and a copy after the frame were two more launches of ~5 us.
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < FS_COUNT; k++) { host_status[k] = status[k]; status[k] = 0u; }
   }
-  __shared__ double rowy[TSY];       // y / sample_rate for each tile row (fp64 division done once)
-  __shared__ double colx[TS];        // x / sample_rate for each tile column
 
-  const int lane = threadIdx.x;
-  const int tx = blockIdx.x % P.tiles_x;
-  const int ty = blockIdx.x / P.tiles_x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // (wave-uniform: kept in a scalar register)
+  TileLds& L = lds_all[wv];
+  float4* const tile = L.tile;
+  double* const rowy = L.rowy;
+  double* const colx = L.colx;
+  const uint32_t tile_id = blockIdx.x * (uint32_t)WPB + (uint32_t)wv;
+  if (tile_id >= P.tiles_x * P.tiles_y) return;           // (the last workgroup of a frame whose tile count is no multiple of WPB)
+  const int tx = (int)(tile_id % P.tiles_x);
+  const int ty = (int)(tile_id / P.tiles_x);
   const int sx0 = tx * (int)P.tile_s, sy0 = ty * (int)P.tile_sy;  // tile origin (samples)
   const int tsw = min((int)P.tile_s, (int)P.ssw - sx0);           // valid extent inside the target
   const int tsh = min((int)P.tile_sy, (int)P.ssh - sy0);
@@ -559,7 +591,6 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
 
   const int lx = lane & (TS - 1);
   const int lrow = lane >> 5;
-  double px = 0.0;  // x / sample_rate (cpp:510), set with the clear
   // Pixel of a sample (lines compare pixels): the tile's origin is a whole pixel (tx * tile_px, ty * tile_py) and the offset inside
   // the tile is below 32, so floor(o / sr) = (int)((o + 0.5) * (1 / sr)) exactly - (o + 0.5) / sr is at least 1 / 64 away from
   // every integer, far more than the rounding of the reciprocal and the product - and no integer division is spent on it.
@@ -572,25 +603,35 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
 
   // this tile's coarse bin: an ordered list of primitive indices
   const uint32_t bin = (uint32_t)(ty / (int)P.coarse_tiles) * P.coarse_x + (uint32_t)(tx / (int)P.coarse_tiles);
-  const uint32_t* __restrict__ list = lists + offs[bin];
+  // A list entry is {primitive, its box clipped to the bin - bin-relative, 4 x 8 bits} (raster_bin_pass<2>): the scan needs no second,
+  // dependent fetch of the box, and what a lane keeps of it across the ordered loop is ONE register - the rectangle inside this tile.
+  // (Bins of more than 256 samples per side - targets beyond ~20 000 pixels - cannot pack: the box then comes from the bbox array.)
+  const uint2* __restrict__ list = reinterpret_cast<const uint2*>(lists) + offs[bin];
   const uint32_t n = counts[bin];
-  // software prefetch: the next 64 (index, bbox) pairs are in flight while the current ones are rasterized
-  uint32_t nidx = 0;
-  int4 nbb = make_int4(1, 1, 0, 0);
-  if ((uint32_t)lane < n) { nidx = list[lane]; nbb = bbox[nidx]; }
+  const int binx0 = (tx / (int)P.coarse_tiles) * (int)(P.coarse_tiles * P.tile_s), biny0 = (ty / (int)P.coarse_tiles) * (int)(P.coarse_tiles * P.tile_sy);
+  // software prefetch: the next 64 entries are in flight while the current ones are rasterized
+  uint2 nent = make_uint2(0u, 0u);
+  if ((uint32_t)lane < n) nent = list[lane];
   for (uint32_t base = 0; base < n; base += WAVE) {
-    const uint32_t myidx = nidx;
-    const int4 bb = nbb;
-    nbb = make_int4(1, 1, 0, 0);
-    if (base + WAVE + lane < n) { nidx = list[base + WAVE + lane]; nbb = bbox[nidx]; }
-    const bool overlaps = (base + lane < n) && (bb.x <= bb.z) && (bb.x <= sx1) && (bb.z >= sx0) && (bb.y <= sy1) && (bb.w >= sy0);
+    const uint32_t myidx = nent.x;
+    int bx0 = binx0 + (int)(nent.y & 255u), by0 = biny0 + (int)((nent.y >> 8) & 255u);
+    int bx1 = binx0 + (int)((nent.y >> 16) & 255u), by1 = biny0 + (int)(nent.y >> 24);
+    if (!P.packed_ok && base + lane < n) { const int4 fb = bbox[myidx]; bx0 = fb.x; by0 = fb.y; bx1 = fb.z; by1 = fb.w; }
+    if (base + WAVE + lane < n) nent = list[base + WAVE + lane];
+    const bool overlaps = (base + lane < n) && (bx0 <= sx1) && (bx1 >= sx0) && (by0 <= sy1) && (by1 >= sy0);
+    // the primitive's rectangle inside the tile, tile-local sample coordinates (each < 32)
+    const uint32_t rect = (uint32_t)(max(bx0, sx0) - sx0) | ((uint32_t)(max(by0, sy0) - sy0) << 8) | ((uint32_t)(min(bx1, sx1) - sx0) << 16) |
+                          ((uint32_t)(min(by1, sy1) - sy0) << 24);
     unsigned long long mask = __ballot(overlaps);
     if (mask != 0ull && !coords) {                       // (uniform) the first candidate of this tile: the tile's sample coordinates
-      if (lane < TSY) rowy[lane] = (double)(sy0 + lane) / (double)P.sr;
-      px = (double)(sx0 + lx) / (double)P.sr;
-      if (lane < TS) colx[lane] = px;
+      // x / sample_rate, y / sample_rate (cpp:510).  For a power-of-two rate the quotient is the product with the exact reciprocal
+      // (both are the exact value, correctly rounded: identical) and two fp64 divisions per lane are not spent on it.
+      const bool pow2 = (P.sr & (P.sr - 1u)) == 0u;
+      const double rs = 1.0 / (double)P.sr;
+      if (lane < TSY) rowy[lane] = pow2 ? (double)(sy0 + lane) * rs : (double)(sy0 + lane) / (double)P.sr;
+      if (lane < TS) colx[lane] = pow2 ? (double)(sx0 + lx) * rs : (double)(sx0 + lx) / (double)P.sr;
       coords = true;
-      __syncthreads();
+      wave_sync();
     }
     // every overlapping lane fetches ITS primitive record now (three 16-byte loads in flight per lane); the ordered
     // loop below then reads records lane by lane with v_readlane instead of paying one memory round trip per primitive
@@ -606,14 +647,14 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
     bool misses = false;
     if (overlaps && q0.x == (uint32_t)SRT_PRIM_TRIANGLE) {
       const float t[6] = {__uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z), __uint_as_float(q1.w)};
-      const double cpx[2] = {colx[max(bb.x, sx0) - sx0], colx[min(bb.z, sx1) - sx0]}, cpy[2] = {rowy[max(bb.y, sy0) - sy0], rowy[min(bb.w, sy1) - sy0]};
+      const double cpx[2] = {colx[rect & 255u], colx[(rect >> 16) & 255u]}, cpy[2] = {rowy[(rect >> 8) & 255u], rowy[rect >> 24]};
       misses = triangle_misses_corners(t, cpx, cpy);
     }
     mask &= ~__ballot(misses);
     if (mask != 0ull && !touched) {                      // (uniform) the first primitive that reaches this tile: clear_target
       for (int i = lane; i < TS * TSY; i += WAVE) tile[i] = white;
       touched = true;
-      __syncthreads();
+      wave_sync();
     }
 
     while (mask) {  // ascending bit order == stream order
@@ -625,10 +666,8 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
       const uint32_t w4 = __builtin_amdgcn_readlane(q1.x, b), w5 = __builtin_amdgcn_readlane(q1.y, b);
       const uint32_t w6 = __builtin_amdgcn_readlane(q1.z, b), w7 = __builtin_amdgcn_readlane(q1.w, b);
       // rectangle of this primitive inside the tile, tile-local sample coordinates
-      const int rx0 = max(__builtin_amdgcn_readlane(bb.x, b), sx0) - sx0;
-      const int ry0 = max(__builtin_amdgcn_readlane(bb.y, b), sy0) - sy0;
-      const int rx1 = min(__builtin_amdgcn_readlane(bb.z, b), sx1) - sx0;
-      const int ry1 = min(__builtin_amdgcn_readlane(bb.w, b), sy1) - sy0;
+      const uint32_t rc = __builtin_amdgcn_readlane(rect, b);
+      const int rx0 = (int)(rc & 255u), ry0 = (int)((rc >> 8) & 255u), rx1 = (int)((rc >> 16) & 255u), ry1 = (int)(rc >> 24);
       const float cr = __uint_as_float(__builtin_amdgcn_readlane(q2.x, b));
       const float cg = __uint_as_float(__builtin_amdgcn_readlane(q2.y, b));
       const float cb = __uint_as_float(__builtin_amdgcn_readlane(q2.z, b));
@@ -642,6 +681,7 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
         const double e0x = bx - ax, e0y = by - ay;  // t0t1
         const double e1x = cx - bx, e1y = cy - by;  // t1t2
         const double e2x = ax - cx, e2y = ay - cy;  // t2t0
+        const double px = colx[lx];                 // (from LDS where it is needed: two registers fewer across the whole scan)
         const double d0x = px - ax, d1x = px - bx, d2x = px - cx;
         // e.y * (p.x - v.x) does not depend on the row: one fp64 product per edge per primitive instead of per sample
         const double k0 = e0y * d0x, k1 = e1y * d1x, k2 = e2y * d2x;
@@ -779,13 +819,15 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
       // no barrier: one wavefront owns the tile and its LDS operations execute in program order
     }
   }
-  __syncthreads();
+  wave_sync();
 
   // resolve (cpp:586-619): box sum with x-offset outer / y-offset inner, true division, truncation
   const int sr = (int)P.sr;
   const int pw = tsw / sr, ph = tsh / sr;
   const int px0 = tx * (int)P.tile_px, py0 = ty * (int)P.tile_py;
   const float denom = (float)((size_t)P.sr * (size_t)P.sr);
+  const bool pow2_sr = (P.sr & (P.sr - 1u)) == 0u;
+  const float inv_denom = 1.0f / denom;
   if (!touched) {                                        // an untouched tile: every pixel (255, 255, 255, 255), every sample 255.0f
     for (int k = lane; k < pw * ph; k += WAVE) rgba_out[(size_t)(py0 + k / pw) * P.w + (px0 + k % pw)] = 0xFFFFFFFFu;
     if (samples_out)
@@ -802,7 +844,8 @@ __global__ __launch_bounds__(WAVE, TSY == 32 ? 2 : ((IMG || TSY == 16) ? SRT_RAS
         r += s.x; g += s.y; bl += s.z; a += s.w;
       }
     }
-    r /= denom; g /= denom; bl /= denom; a /= denom;
+    if (pow2_sr) { r *= inv_denom; g *= inv_denom; bl *= inv_denom; a *= inv_denom; }   // (exact scaling: the same value as the division)
+    else { r /= denom; g /= denom; bl /= denom; a /= denom; }
     const uint32_t R = (uint32_t)(uint8_t)(r), G = (uint32_t)(uint8_t)(g), B = (uint32_t)(uint8_t)(bl),
                    A = (uint32_t)(uint8_t)(a);
     rgba_out[(size_t)(py0 + pyl) * P.w + (px0 + pxl)] = R | (G << 8) | (B << 16) | (A << 24);
@@ -846,7 +889,7 @@ struct srt_raster {
   srt_prim* d_prims = nullptr;
   int4* d_bbox = nullptr;
   size_t d_cap = 0;
-  uint32_t* d_lists = nullptr; size_t lists_cap = 0;   // coarse-bin lists, packed (raster_bin_pass<2>); kept across frames and streams
+  uint2* d_lists = nullptr; size_t lists_cap = 0;      // coarse-bin lists, packed back to back (raster_bin_pass<2>), entries of {primitive, box}; kept across frames and streams
   uint32_t* d_counts = nullptr; size_t counts_cap = 0; // per coarse bin: entries, then (second half) list offsets
   uint32_t* d_super = nullptr; size_t super_cap = 0;   // super-bin lists (<= 64 x nprims) followed by their 64 counts
   bool bins_valid = false;                             // the bin lists on the device belong to the current stream / target / tiling
@@ -1093,6 +1136,7 @@ void set_grid(RasterParams& P, uint32_t c) {
   P.super_bx = (P.coarse_x + 7) / 8; P.super_by = (P.coarse_y + 7) / 8;
   P.super_x = (P.coarse_x + P.super_bx - 1) / P.super_bx; P.super_y = (P.coarse_y + P.super_by - 1) / P.super_by;
   P.super_stride = P.nprims ? P.nprims : 1;
+  P.packed_ok = (c * P.tile_s <= 256u && c * P.tile_sy <= 256u) ? 1u : 0u;
 }
 
 // Enqueue one frame of the current stream on `s`: raster_setup + the two ordered binning passes when the lists on the device
@@ -1129,14 +1173,14 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
     // Ordered binning (raster_bin_pass): coarse bins of c x c tiles under <= 8 x 8 super-bins
     uint32_t* d_super_counts = r->d_super + ns * P.super_stride;
     raster_bin_pass<1><<<dim3((unsigned)ns), dim3(1024), 0, s>>>(P, r->d_bbox, nullptr, nullptr, r->d_super, d_super_counts, nullptr, 0u, r->d_status, r->d_prims);
-    raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, r->d_lists, r->d_counts, r->d_counts + nb,
+    raster_bin_pass<2><<<dim3((unsigned)nb), dim3(256), 0, s>>>(P, r->d_bbox, r->d_super, d_super_counts, reinterpret_cast<uint32_t*>(r->d_lists), r->d_counts, r->d_counts + nb,
                                                                 (uint32_t)std::min<size_t>(r->lists_cap, 0xFFFFFFFFull), r->d_status, r->d_prims);
     r->bins_valid = true;
   }
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
 #define SRT_TILES2(STATS_, TSY_, IMG_, ST_)                                                                                 \
-  raster_tiles<STATS_, TSY_, IMG_><<<dim3(ntiles), dim3(WAVE), 0, s>>>(P, r->d_prims, r->d_bbox, r->d_lists, r->d_counts,       \
+  raster_tiles<STATS_, TSY_, IMG_><<<dim3((ntiles + (TSY_ == 32 ? 1 : kTileWavesPerBlock) - 1) / (TSY_ == 32 ? 1 : kTileWavesPerBlock)), dim3(WAVE * (TSY_ == 32 ? 1 : kTileWavesPerBlock)), 0, s>>>(P, r->d_prims, r->d_bbox, reinterpret_cast<const uint32_t*>(r->d_lists), r->d_counts, \
                                                                  r->d_counts + (size_t)P.coarse_x * P.coarse_y, r->d_aux,       \
                                                                  r->d_tabs, r->d_texels, r->d_laux, r->d_ltable, r->d_rgba, so, ST_, r->d_status, r->d_host_status)
 #define SRT_TILES(STATS_, TSY_, ST_) do { if (r->has_images) SRT_TILES2(STATS_, TSY_, true, ST_); else SRT_TILES2(STATS_, TSY_, false, ST_); } while (0)
@@ -1508,7 +1552,7 @@ int srt_raster_stats(srt_raster* r, srt_raster_stats_t* out) {
   out->fragments = h[ST_FRAGMENTS];
   out->point_samples = h[ST_POINT_SAMPLES];
   out->bin_entries = h[ST_BIN_ENTRIES];
-  out->list_bytes = (uint64_t)(r->super_cap + r->lists_cap + r->counts_cap) * sizeof(uint32_t);
+  out->list_bytes = (uint64_t)(r->super_cap + r->counts_cap) * sizeof(uint32_t) + (uint64_t)r->lists_cap * sizeof(uint2);
   return SRT_OK;
 }
 

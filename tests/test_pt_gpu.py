@@ -804,6 +804,20 @@ def test_device_bvh_build_equals_host_build(srt, scene_name, min_prims):
         assert bits_equal(bh, bd) and np.array_equal(lh, ld) and np.array_equal(oh, od)
     org, d, b = random_rays(91, 1024)
     assert bits_equal(pt_h.hit(org, d, b), pt_d.hit(org, d, b))
+    # ... and, directly, the REFERENCE build's node arrays of the same scene (the goldens of tests/golden/make_pt_golden.py)
+    gpath = glob.glob(os.path.join(H.GOLDEN, f"pt_{scene_name}_*_bvh.npz"))
+    assert gpath, scene_name
+    g = np.load(gpath[0])
+    assert scene_digest(scene) == str(g["scene_sha256"])
+    boxes, links, order = pt_d.dump_bvh(-1)
+    assert bits_equal(boxes, g["tlas_boxes"]) and np.array_equal(links, g["tlas_links"]) and np.array_equal(order[: len(scene["objects"])], g["tlas_order"])
+    checked = 0
+    for k in range(len(scene["objects"])):
+        try:
+            checked += bool(H.check_blas_against_golden(g, k, pt_d.dump_bvh))
+        except srt.SrtError:
+            pass                                             # an object slot without a mesh
+    assert checked >= 1, "no BVH<Triangle> of this scene was compared with the reference's"
     pt_h.close(); pt_d.close()
 
 

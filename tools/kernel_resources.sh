@@ -1,25 +1,24 @@
 #!/bin/bash
-# Registers / scratch / LDS of every kernel in a built object (default: the path tracer), read from the code object's notes.
+# Per-kernel registers / scratch / occupancy of csrc/pt.hip (or the file given) as the compiler reports them - no GPU needed:
+#   bash tools/kernel_resources.sh [file.hip] [filter-regex]
+# (-Rpass-analysis=kernel-resource-usage; the object goes to /tmp).  What DESIGN.md's spill and occupancy figures are read from.
 set -e
-OBJ=${1:-$(dirname "$0")/../soft-rendering-toolsets_amd/lib/pt.hip.o}
-LLVM=/opt/rocm/lib/llvm/bin
-TMP=$(mktemp -d)
-$LLVM/llvm-objcopy --dump-section .hip_fatbin=$TMP/fat.bin "$OBJ"
-$LLVM/clang-offload-bundler --unbundle --type=o --input=$TMP/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$TMP/k.hsaco
-$LLVM/llvm-readelf --notes $TMP/k.hsaco | python3 -c "
-import sys, re
-cur = {}
-def flush():
-    if cur.get('.name'):
-        print('%-70s vgpr %4s agpr %3s sgpr %4s scratch %5s lds %6s spill v/s %s/%s' % (cur['.name'][:70], cur.get('.vgpr_count'), cur.get('.agpr_count'), cur.get('.sgpr_count'),
-              cur.get('.private_segment_fixed_size'), cur.get('.group_segment_fixed_size'), cur.get('.vgpr_spill_count'), cur.get('.sgpr_spill_count')))
-for l in sys.stdin:
-    m = re.match(r'\s*-?\s*(\.[a-z_]+):\s*(\S+)', l)
-    if not m: continue
-    k, v = m.groups()
-    if k == '.agpr_count' and cur.get('.name') and '.agpr_count' in cur: pass
-    if k in cur and k in ('.agpr_count',) : flush(); cur.clear()
-    cur[k] = v
-    if k == '.wavefront_size': flush(); cur.clear()
-"
-rm -rf $TMP
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=${1:-pt.hip}
+filter=${2:-pt_wave_kernel|pt_cast_kernel|raster_tiles|raster_bin|raster_setup}
+cd "$root/soft-rendering-toolsets_amd/csrc"
+hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize --offload-arch=gfx950 -I../../include \
+      -Wno-unused-function $EXTRA -Rpass-analysis=kernel-resource-usage -c "$src" -o /tmp/kres.o > /tmp/kres.log 2>&1 || { tail -20 /tmp/kres.log; exit 1; }
+python3 - "$filter" <<'PY'
+import re, subprocess, sys
+txt = open('/tmp/kres.log').read()
+for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
+    name = b.split('\n')[0].split(' [')[0]
+    d = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
+    short = re.sub(r"\(.*", "", d).replace("void srt::", "").replace("void (anonymous namespace)::", "")
+    if not re.search(sys.argv[1], short):
+        continue
+    g = lambda k: (re.search(re.escape(k) + r": (\d+)", b) or [0, -1])[1]
+    v, sc, oc, sg, ld = g('VGPRs'), g('ScratchSize [bytes/lane]'), g('Occupancy [waves/SIMD]'), g('SGPRs'), g('LDS Size [bytes/block]')
+    print(f"{short:60s} vgpr {v:>4} scratch {sc:>5} B/lane  occupancy {oc}  sgpr {sg}  lds {ld}")
+PY
