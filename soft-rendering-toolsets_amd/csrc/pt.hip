@@ -652,6 +652,7 @@ int render_epoch_wave(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sample_
     P.flat_interior = getenv("SRT_FLAT_INTERIOR") ? (uint32_t)atoi(getenv("SRT_FLAT_INTERIOR")) : kFlatInteriorMin;
     P.queue_head = B.d_queue; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1; P.stamps = B.d_queue + 1;
     P.host_cancel = pt->d_host_cancel; P.dev_cancel = B.d_cancel;
+    P.watch = (pt->wave_blocks >= 2 && !getenv("SRT_NO_CANCEL_WATCH")) ? 1u : 0u;   // the last workgroup watches for srt_pt_cancel (pt_wave.h; the variable: A/B runs)
     if (n) {
       SRT_HIP(hipMemsetAsync(B.d_queue, 0, sizeof(unsigned long long), s));
       const DScene DS = device_scene(pt, &B);

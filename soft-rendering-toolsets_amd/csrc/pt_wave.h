@@ -83,11 +83,15 @@ struct WaveParams {
   uint32_t obj_shift;        // packed hit = object slot << obj_shift | triangle
   // srt_pt_cancel (Pathtracer::cancel, rays/pathtracer.cpp:282-290 - the reference tests cancel_flag after every sample, :224):
   // host_cancel is the context's flag in pinned, device-visible host memory; dev_cancel the stream's sticky copy in device
-  // memory, which every wave of every kernel of the epoch reads once, at its start.  ONE wave of a persistent launch looks at the
-  // host word whenever it fetches work, and on seeing it set raises dev_cancel and moves the unit queue's head past its end:
-  // every other wave then finds the queue drained at its next fetch - no wave pays for a read over PCIe in its loop.
+  // memory, which every wave of every kernel of the epoch reads once, at its start.  A persistent launch gives up ONE of its
+  // workgroups (0.1 % of its lanes) as the WATCHER: its first lane looks at the host word every few microseconds and, on seeing
+  // it set, raises dev_cancel and moves the unit queue's head past its end - every tracing wave then finds the queue drained at
+  // its next fetch.  Nothing in the tracing waves' loop knows about cancels: a poll in their fetch path, executed by one wave
+  // only, still cost the loop 0.8 % (A/B in round 4: the branch alone changed the register allocation), and a DMA transfer from
+  // the host onto the queue head never reached the launch (its atomics run on the line the L2 holds).
   const uint32_t* host_cancel;
   uint32_t* dev_cancel;
+  uint32_t watch;            // persistent launches: the last workgroup is the cancel watcher (needs >= 2 workgroups)
   // streamed forms: the alive slots of the previous generation in ascending order (pt_compact_kernel); lane i of generation g >= 1
   // works on slot alive_list[i], i < sc->alive_n[g & 1].  Generation 0 (every slot idle) works on slot = lane.
   const uint32_t* alive_list;
@@ -520,6 +524,24 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
     if (P_in.sc->done != 0u) return;                     // every unit is finished: the remaining generations are no-ops
   }
   if (cancel_raised(P_in.dev_cancel)) return;            // srt_pt_cancel: what is left of the epoch is not rendered
+  if constexpr (!STREAM) {
+    // The cancel watcher (WaveParams::watch): the launch's last workgroup traces nothing.  Its first lane sleeps, looks at the host's
+    // flag, sleeps - until the flag is up (then: the stream's cancel word, and the queue head past its end) or every unit has been
+    // handed out (a cancel later than that has nothing left to stop).  Both ends are reached whatever the other workgroups do.
+    if (P_in.watch != 0u && blockIdx.x == gridDim.x - 1u) {
+      if (threadIdx.x != 0u) return;
+      for (;;) {
+        if (cancel_requested(P_in.host_cancel)) {
+          atomicExch(P_in.dev_cancel, 1u);
+          atomicMax(P_in.queue_head, kQueuePoison);
+          return;
+        }
+        if (__hip_atomic_load(P_in.queue_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)P_in.total_units) return;
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+      }
+    }
+  }
   DScene S = S_in;
   S.objects = a_objects; S.tris = a_tris; S.tri_nrm = a_nrm; S.nodes = a_nodes; S.lights = a_lights;
   S.light_tris = a_ltris; S.materials = a_mats; S.wave_tlas = a_wave; S.blas_recs = a_blas;
@@ -758,10 +780,6 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
           unsigned long long start = 0;
           const uint32_t grab = P.chunk;
           if (lane == 0) {
-            if (blockIdx.x == 0u && wave == 0 && cancel_requested(P.host_cancel)) {      // (this wave looks for the others)
-              atomicExch(P.dev_cancel, 1u);
-              atomicMax(P.queue_head, kQueuePoison);
-            }
             start = atomicAdd(P.queue_head, (unsigned long long)grab);
           }
           start = __shfl(start, 0);
@@ -1314,14 +1332,11 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
         actA = true;
         actB = !discrete;
         V3 chosen = world_in;
+        bool log_fire = false;
         if (!discrete) {
           const V3 to_light = light_sample(S, sf.position, rng);
           chosen = rng.coin(0.5f) ? world_in : to_light;
-          // log_ray(world_ray_task6, 5.0f) with probability 0.0005 (student/pathtracer.cpp:148): the coin is always drawn
-          if (rng.coin(0.0005f) && S.ray_log) {
-            const V3 ld = unit(chosen);
-            log_ray_event(S.ray_log, S.ray_log_cap, sf.position.x, sf.position.y, sf.position.z, ld.x, ld.y, ld.z, rng.inc, level);
-          }
+          log_fire = rng.coin(0.0005f);                 // log_ray(world_ray_task6, 5.0f) with probability 0.0005 (student/pathtracer.cpp:148)
           pdf_area = light_pdf<false>(S, sf.position, to_light, cnt);
         }
         if (m.type == 0) { s2.atten = s1.atten; s2.dir = lambert_direction(rng); }
@@ -1340,6 +1355,14 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
         d[C] = unit(world_in2);
         cb0 = kEps; cb1 = FLT_MAX;
         need_begin = true;
+#ifndef SRT_AB_NOLOG                                   // (A/B builds only: what the ray log costs the loop)
+        // the logged ray is the MIS direct ray just set up - Ray(hit.pos, random_in_dir): origin and unit direction are in their
+        // final registers here, nothing is computed for the log that the batch does not need anyway
+        if (log_fire && S.ray_log) {
+          const V3 ld = d[NR == 3 ? 1 : 0];
+          log_ray_event(S.ray_log, S.ray_log_cap, org.x, org.y, org.z, ld.x, ld.y, ld.z, rng.inc, level - 1u);
+        }
+#endif
       }
     }
     SECTION_END(ST_SHADE)

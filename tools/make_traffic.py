@@ -58,6 +58,19 @@ def per_epoch(path, epochs, only_three_ray=True):
     return {c: v / epochs for c, v in sums.items()}
 
 
+def per_kernel(path, epochs, counter, scale):
+    """kernel (short name) -> bytes per epoch of `counter` (works on raw and on reduced counter files)"""
+    out = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter or not any(k in row["Kernel_Name"] for k in KERNELS + ("pt_reduce_kernel",)):
+                continue
+            v = float(row["Sum"]) if "Sum" in row else float(row["Counter_Value"])
+            name = row["Kernel_Name"].replace("void ", "").replace("srt::", "").split("(")[0]
+            out[name] = out.get(name, 0.0) + v * scale / epochs
+    return out
+
+
 def main():
     out, tag = sys.argv[1], sys.argv[2]
     sq_dir = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
@@ -94,6 +107,9 @@ def main():
         "hbm_read_bytes_per_launch": fetch_b,
         "hbm_write_bytes_per_launch": write_b,
         "hbm_bytes_per_launch": fetch_b + write_b,
+        # the same split by kernel (bytes per epoch): which kernel's reads and writes the total is made of
+        "per_kernel_read_bytes": per_kernel(fetch, epochs, "FETCH_SIZE", 2048.0),
+        "per_kernel_write_bytes": per_kernel(write, epochs, "WRITE_SIZE", 1024.0),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes of "
                   f"`bench.py --scene {scene} --steps 2 --warmup 0 --no-cpu-baseline --no-raster --no-cfg5 --no-overlap --no-elision` "
                   "(2 timed + 2 measuring epochs), summed over the path tracer's kernels and divided by the epochs; FETCH_SIZE doubled per the "
