@@ -667,8 +667,8 @@ def group_bench(args):
         base_sha = base_sha or sha
         want = None
         if (args.scene, W, args.depth, args.seed, spp) == ("cbox", 1024, 8, 0, 64):
-            import _harness as H
-            want = H.load_fullsize().get("cfg4_cbox_1024_64spp")
+            import _harness as harness                   # (H is the image height here)
+            want = harness.load_fullsize().get("cfg4_cbox_1024_64spp")
         # rank 0's kernel against the issue ceiling / SURVEY.md 8(d)'s byte figure, as in the headline (counters only at N = 1)
         rng = np.random.default_rng(1)
         k = 1 << 14
@@ -707,6 +707,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster", action="store_true")
+    ap.add_argument("--no-golden-check", action="store_true", help="skip the extra epoch whose image is compared with the reference-built golden (profiling passes)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the object that times the PT::Pathtracer class end to end")
     ap.add_argument("--no-elision", action="store_true", help="skip the extra pass that measures dead-ray elision")
     ap.add_argument("--no-overlap", action="store_true", help="every step on one stream (no overlap of consecutive launches)")
@@ -836,7 +837,7 @@ def main():
     # whether its N ranks and its collective reproduce that image bit for bit.
     golden = None
     gkey = "cfg4_cbox_1024_64spp"
-    if args.scene == "cbox" and (W, args.depth) == (1024, 8):
+    if args.scene == "cbox" and (W, args.depth) == (1024, 8) and not args.no_golden_check:
         import hashlib
 
         import _harness as harness                     # (H is the image height here)

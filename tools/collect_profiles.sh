@@ -27,7 +27,7 @@ if [ "$scene" = raster ]; then
   python3 tools/make_raster_profile.py "$out" "$tag"
   exit 0
 fi
-common="--scene $scene --no-cpu-baseline --no-cfg5 --no-overlap --no-dropin"
+common="--scene $scene --no-cpu-baseline --no-cfg5 --no-overlap --no-dropin --no-golden-check"
 cd /tmp
 if [ "$scene" = cbox ]; then statsopt="--steps 8 --warmup 1"; else statsopt="--steps 2 --warmup 1 --no-raster --no-elision"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 "$root/bench.py" $statsopt $common > "$out/stats.log" 2>&1
