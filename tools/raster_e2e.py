@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""DrawSVG's redraw through the drop-in class (oracle/_ref/libdropin_raster.so), wall clock: the three figures bench.py reports as
+"""DrawSVG's redraw through the drop-in class (integration/_build/libdropin_raster.so), wall clock: the three figures bench.py reports as
 raster.draw_svg, over more frames.  usage: raster_e2e.py [frames] [svg] [w h sr]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ import _harness as H
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 svg = sys.argv[2] if len(sys.argv) > 2 else os.path.join(H.GOLDEN, "svg", "test3.svg")
 w, h, sr = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (1024, 1024, 4)
-lib = ctypes.CDLL(os.path.join(H.ORACLE_DIR, "_ref", "libdropin_raster.so"))
+lib = ctypes.CDLL(os.path.join(H.ROOT, "integration", "_build", "libdropin_raster.so"))
 ms = (ctypes.c_double * 5)()
 out = np.zeros((h, w, 4), np.uint8)
 for rep in range(3):
