@@ -700,12 +700,13 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
   }
 
   bool refilled = false;                                 // PHASE 2: the slot took a new unit in this generation
+  bool retry = false;                                    // streamed: the unit the slot took was a padding pixel - it must come back for another
   auto save_state = [&]() {
     if (!has_slot) return;                               // (a lane past the end of the alive list serves no slot)
     if constexpr (PHASE == 2) {
       // the probe kernel changes a slot's state only by giving it a new unit: the words the refill sets (the parked hits, the RNG
       // state and the shading terms are written by the resolve kernel before anything reads them)
-      ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));
+      ST_SET(SW_EMIT, emit_mask | ((alive || retry) ? 0x80000000u : 0u));   // (bit 31: the slot stays on the alive list)
       if (refilled) {
         ST_SET(SW_FLAGS, 1u | 2u | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (level << 8) | (depth << 16));
         ST_SET(SW_PX, PX_); ST_SET(SW_PY, PY_); ST_SET(SW_PIXEL_SLOT, pixel_slot);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
     }
     ST_SET(SW_FLAGS, (alive ? 1u : 0u) | (burst ? 2u : 0u) | (actA ? 4u : 0u) | (actB ? 8u : 0u) | (discrete ? 16u : 0u) |
                    (sh_phase ? 32u : 0u) | (sa1 ? 64u : 0u) | (sa2 ? 128u : 0u) | (level << 8) | (depth << 16));
-    if constexpr (PHASE == 0) ST_SET(SW_EMIT, emit_mask | (alive ? 0x80000000u : 0u));   // (bit 31: the slot is alive - a generation without requests need not be the last; PHASE 1: the probe kernel writes it)
+    if constexpr (PHASE == 0) ST_SET(SW_EMIT, emit_mask | ((alive || retry) ? 0x80000000u : 0u));   // (bit 31: the slot stays on the alive list - alive, or it drew a padding pixel and must draw again; a generation without requests need not be the last; PHASE 1: the probe kernel writes it)
     if (alive) {
       ST_SET(SW_PX, PX_); ST_SET(SW_PY, PY_); ST_SET(SW_PIXEL_SLOT, pixel_slot);
       ST_SET(SW_SAMPLES, samp);
@@ -830,6 +831,7 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
           refilled = true;
         } else {
           units_finished++;                             // a padding pixel of an edge tile: nothing to render
+          retry = true;                                 // (the slot is idle but NOT for lack of units: it stays on the alive list)
         }
       }
     }

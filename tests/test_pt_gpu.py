@@ -960,3 +960,23 @@ def test_cancel_ends_an_epoch_in_flight(srt, scene_name, size, spp):
     want = fresh.render_epoch(5, 3, 2)
     assert bits_equal(got, want)
     pt.close(); fresh.close()
+
+
+@pytest.mark.parametrize("w,h,slots", [(40, 24, 256), (70, 45, 512), (33, 33, 256)])
+def test_streamed_forms_with_padding_pixels_and_a_small_population(srt, w, h, slots):
+    """Images whose sides are no multiples of the 32 x 32 tiles hand out PADDING units (pixels of an edge tile outside the image): a path
+    slot that draws one has nothing to render and must draw again in the next generation - with the alive-slot list of round 4 it
+    has to stay on that list although it is idle (found by tools/fuzz_pt.py: with a small population the launch ran out of slots and
+    ended with unfinished units).  Both streamed forms, populations far smaller than the unit count, against the oracle."""
+    scene = pt_scene("cbox_blob512_glass")
+    spp = 7
+    want = H.OraclePT(scene, w, h, 6, True).epoch(9, 2, spp)
+    pt = make_pt(srt, scene, w, h, 6, True)
+    pt.set_stream_slots(slots)
+    for mode in (6, 7):
+        for elide in (False, True):
+            pt.set_kernel(mode)
+            pt.set_elision(elide)
+            assert pt.kernel_form() in (3, 4)
+            assert bits_equal(pt.render_epoch(9, 2, spp), want), (mode, elide)
+    pt.close()
