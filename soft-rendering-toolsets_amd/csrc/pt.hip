@@ -777,8 +777,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       const uint32_t nblocks = nlanes / lthreads;
       if ((st = ensure(&B.d_records, &B.records_floats, (size_t)nlanes * kRecFields * kMaxPathDepth)) != SRT_OK) return st;
       if ((st = ensure(&B.d_state, &B.state_words, (size_t)nlanes * SW_DL_WORDS)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_ray_o, &B.ray_o_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
-      if ((st = ensure(&B.d_ray_d, &B.ray_d_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
+      if ((st = ensure(&B.d_ray_o, &B.ray_o_n, 2 * (size_t)nlanes * nslots)) != SRT_OK) return st;   // {origin, direction} per request
       if ((st = ensure(&B.d_ray_id, &B.ray_id_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
       if ((st = ensure(&B.d_hits, &B.hits_n, (size_t)nlanes * nslots)) != SRT_OK) return st;
       if ((st = ensure(&B.d_alive_list, &B.alive_list_n, (size_t)nlanes)) != SRT_OK) return st;
@@ -789,7 +788,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       P.sample_out = B.d_samples; P.records = B.d_records; P.npix = px; P.chunk = kChunk;
       P.queue_head = &B.d_sc->queue_head; P.ray_counter = pt->d_totals + C_COUNT; P.elided_counter = pt->d_totals + C_COUNT + 1;
       P.stamps = nullptr; P.flat_ready = 0; P.flat_interior = 0;
-      P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_d; P.hits = B.d_hits; P.sc = B.d_sc;
+      P.state = B.d_state; P.ray_o = B.d_ray_o; P.ray_d = B.d_ray_o + 1; P.hits = B.d_hits; P.sc = B.d_sc;
       P.block_counters = B.d_block_counters;
       P.obj_shift = stream_obj_shift(F);
       P.host_cancel = pt->d_host_cancel; P.dev_cancel = B.d_cancel;
@@ -800,7 +799,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       const uint64_t M = 1ull + (uint64_t)burst * pt->max_depth * (1ull + (dl ? shadow_batches : 0ull));
       const uint64_t gens = ((uint64_t)P.total_units * M + nlanes - 1) / nlanes + M + 2;
       CastParams C{};
-      C.ray_o = B.d_ray_o; C.ray_d = B.d_ray_d; C.ray_id = B.d_ray_id; C.hits = B.d_hits; C.nlanes = nlanes;
+      C.ray_o = B.d_ray_o; C.ray_d = B.d_ray_o + 1; C.ray_id = B.d_ray_id; C.hits = B.d_hits; C.nlanes = nlanes;
       C.depth = depth; C.lds_frames = pt->cast_lds_frames; C.spill = B.d_cast_spill; C.obj_shift = P.obj_shift; C.sc = B.d_sc; C.total_units = P.total_units;
       C.walk_nr = trav == 4 ? burst : 0u;
       for (size_t i = 0; i < F.lazy_objects.size() && i < 4; i++) C.lazy_obj[i] = F.lazy_objects[i];

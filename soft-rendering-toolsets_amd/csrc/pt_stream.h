@@ -111,8 +111,9 @@ struct LdsStack {
 };
 
 struct CastParams {
-  const float4* ray_o;       // [queue slot * nlanes + path slot] origin, dist_bounds.x
-  const float4* ray_d;       // [same] direction, dist_bounds.y
+  const float4* ray_o;       // [2 * (queue slot * nlanes + path slot)] origin, dist_bounds.x
+  const float4* ray_d;       // = ray_o + 1, same index: direction, dist_bounds.y - a request is ONE 32-byte piece (round 4; two planes were two
+                             // partial lines per request on the way in and on the way out)
   const uint32_t* ray_id;    // dense list of the positions that carry a ray this generation (pt_compact_kernel)
   uint2* hits;               // [same position] {distance bits, object << obj_shift | triangle, or 0xFFFFFFFF}
   uint32_t nlanes;
@@ -421,8 +422,8 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
         const uint32_t idx = start + rank;
         if (F.mode == FM_DONE && rank < take && idx < nrays) {
           my_id = __builtin_nontemporal_load(P.ray_id + idx);
-          const f32x4 ro = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_o) + my_id);
-          const f32x4 rd = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_d) + my_id);
+          const f32x4 ro = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_o) + 2u * (size_t)my_id);
+          const f32x4 rd = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.ray_d) + 2u * (size_t)my_id);
           wo = v3(ro.x, ro.y, ro.z); wd = v3(rd.x, rd.y, rd.z); wb0 = ro.w; wb1 = rd.w;
           if (WALK) {
             // a walk request: the lane starts inside the mesh's tree, as flat_object leaves it there (Tri_Mesh::hit ->

@@ -74,8 +74,9 @@ struct WaveParams {
   uint32_t flat_interior;    // TRAV 2: lanes at interior nodes that keep the wave in the interior-step loop       // STAMP build only: per-section cycle sums
   // TRAV 3 (streamed form, pt_stream.h): one invocation = one generation; nlanes = path slots
   uint32_t* state;           // [word][slot] saved path state
-  float4* ray_o;             // rays / walk requests of this generation at FIXED positions: [queue slot][path slot]
-  float4* ray_d;             //   TRAV 3: queue slot = batch slot; TRAV 4: queue slot = mesh ordinal * NR + batch slot
+  float4* ray_o;             // rays / walk requests of this generation at FIXED positions: [2 * ([queue slot][path slot])], and
+  float4* ray_d;             //   ray_d = ray_o + 1 (origin and direction of a request side by side: one 32-byte piece);
+                             //   TRAV 3: queue slot = batch slot; TRAV 4: queue slot = mesh ordinal * NR + batch slot
   const uint2* hits;         // [queue slot][path slot] results of the previous generation's rays / walks
   StreamCounters* sc;
   unsigned long long* block_counters;   // [block][2]: rays counted / rays elided by that block of the logic kernel, all generations
@@ -259,8 +260,8 @@ SRT_DEV void object_testN(const DScene& S, uint32_t k, V3 org, const V3* d, cons
       if (need[r]) {
         const size_t pos = (size_t)(m * (uint32_t)NR + (uint32_t)r) * QP->nlanes + lane_global;
         if (emit) {
-          QP->ray_o[pos] = make_float4(oorg.x, oorg.y, oorg.z, ob0[r]);
-          QP->ray_d[pos] = make_float4(od[r].x, od[r].y, od[r].z, ob1[r]);
+          QP->ray_o[2 * pos] = make_float4(oorg.x, oorg.y, oorg.z, ob0[r]);
+          QP->ray_d[2 * pos] = make_float4(od[r].x, od[r].y, od[r].z, ob1[r]);
           *emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
         } else {
           const uint2 hv = QP->hits[pos];
@@ -434,8 +435,8 @@ SRT_DEV void object_queueN(const DScene& S, uint32_t k, V3 org, const V3* d, con
       const bool hl = box_hit_rec(root.boxl, oorg, cinv, ta, tb);
       const bool hr = box_hit_rec(root.boxr, oorg, cinv, tc, td);
       if (hl || hr) {
-        nt_store_ray(QP.ray_o, pos, oorg.x, oorg.y, oorg.z, ob0[r]);
-        nt_store_ray(QP.ray_d, pos, od[r].x, od[r].y, od[r].z, ob1[r]);
+        nt_store_ray(QP.ray_o, 2 * pos, oorg.x, oorg.y, oorg.z, ob0[r]);
+        nt_store_ray(QP.ray_d, 2 * pos, od[r].x, od[r].y, od[r].z, ob1[r]);
         emit_mask |= 1u << (m * (uint32_t)NR + (uint32_t)r);
       } else {
         __builtin_nontemporal_store(u32x2_t{0u, 0xFFFFFFFFu}, reinterpret_cast<u32x2_t*>(const_cast<uint2*>(QP.hits)) + pos);
@@ -854,8 +855,8 @@ __global__ __launch_bounds__(256, PHASE == 2 ? SRT_PROBE_OCC : TRAV == 4 ? SRT_S
         for (int r = 0; r < NR; r++) {
           if (eact[r]) {
             const size_t i = (size_t)r * P.nlanes + lane_global;
-            nt_store_ray(P.ray_o, i, org.x, org.y, org.z, cb0);
-            nt_store_ray(P.ray_d, i, d[r].x, d[r].y, d[r].z, eb1[r]);
+            nt_store_ray(P.ray_o, 2 * i, org.x, org.y, org.z, cb0);
+            nt_store_ray(P.ray_d, 2 * i, d[r].x, d[r].y, d[r].z, eb1[r]);
             emit_mask |= 1u << r;
           }
         }
