@@ -315,6 +315,7 @@ struct srt_pt {
   uint32_t tiles_per_rank = 0;
   // device copies
   Node* d_nodes = nullptr; Tri* d_tris = nullptr; TriNrm* d_nrm = nullptr; Object* d_objects = nullptr;
+  float* d_tri_packed = nullptr;                                 // the triangle records without padding (pt_scene.h): what the cast kernel reads
   Light* d_lights = nullptr; LightTri* d_ltris = nullptr; Material* d_mats = nullptr;
   WaveInterior* d_wave = nullptr; WaveInterior* d_blas = nullptr; uint32_t* d_wave_lazy = nullptr;
   DeltaLight* d_dlights = nullptr;
@@ -816,6 +817,7 @@ int render_epoch_stream(srt_pt* pt, hipStream_t s, uint64_t seed, uint32_t sampl
       if (C.leaf_min < 1u) C.leaf_min = 1u;
       if (C.object_min < 1u) C.object_min = 1u;
       C.stats = pt->d_cast_stats;
+      C.tri_packed = pt->d_tri_packed;
       C.dev_cancel = B.d_cancel;
       const dim3 lgrid(nblocks), lblock(lthreads);
       const dim3 cgrid((nlanes + kCompactChunk - 1) / kCompactChunk);
@@ -948,7 +950,7 @@ int srt_pt_destroy(srt_pt* pt) {
         for (int i = 0; i < CS_COUNT; i++) fprintf(stderr, "[srt] cast %s %llu\n", names[i], h[i]);
       (void)hipFree(pt->d_cast_stats);
     }
-    (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
+    (void)hipFree(pt->d_nodes); (void)hipFree(pt->d_tris); (void)hipFree(pt->d_tri_packed); (void)hipFree(pt->d_nrm); (void)hipFree(pt->d_objects);
     (void)hipFree(pt->d_lights); (void)hipFree(pt->d_ltris); (void)hipFree(pt->d_mats); (void)hipFree(pt->d_wave); (void)hipFree(pt->d_blas); (void)hipFree(pt->d_wave_lazy); (void)hipFree(pt->d_dlights); (void)hipFree(pt->d_env_map);
     (void)hipFree(pt->d_tile_buf); (void)hipFree(pt->d_image); (void)hipFree(pt->d_totals);
     if (pt->h_fault) (void)hipHostFree(pt->h_fault);
@@ -1094,6 +1096,7 @@ int srt_pt_scene_commit(srt_pt* pt, int use_bvh) {
     SRT_HIP(hipStreamSynchronize(pt->stream));
     int st;
     if ((st = upload(&pt->d_nodes, F.nodes)) || (st = upload(&pt->d_tris, F.tris)) || (st = upload(&pt->d_nrm, F.tri_nrm)) ||
+        (st = upload(&pt->d_tri_packed, F.tri_packed)) ||
         (st = upload(&pt->d_objects, F.objects)) || (st = upload(&pt->d_lights, F.lights)) ||
         (st = upload(&pt->d_ltris, F.light_tris)) || (st = upload(&pt->d_mats, F.materials)) ||
         (st = upload(&pt->d_wave, F.wave_tlas)) || (st = upload(&pt->d_blas, F.blas_recs)) || (st = upload(&pt->d_wave_lazy, F.wave_lazy)) ||

@@ -367,6 +367,9 @@ std::string build_scene(const std::vector<ObjectInput>& objects, const std::vect
       }
       F.tris.push_back(g);
       F.tri_nrm.push_back(nn);
+      for (int a = 0; a < 3; a++) F.tri_packed.push_back(g.p0[a]);
+      for (int a = 0; a < 3; a++) F.tri_packed.push_back(g.e1[a]);
+      for (int a = 0; a < 3; a++) F.tri_packed.push_back(g.e2[a]);
     }
   };
   for (uint32_t slot = 0; slot < nobj; slot++) {

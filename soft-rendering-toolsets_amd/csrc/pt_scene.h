@@ -104,6 +104,9 @@ struct FlatScene {
   uint32_t tlas_nodes = 0;
   std::vector<Tri> tris;
   std::vector<TriNrm> tri_nrm;
+  // The same records without their padding (nine floats: p0, e1, e2): what the streamed forms' cast kernel reads (pt_stream.h) - a big
+  // mesh's triangles are most of what its walks miss their XCD's L2 with, and a leaf's <= 4 triangles are 144 bytes this way, 192 padded.
+  std::vector<float> tri_packed;
   std::vector<Object> objects;    // BVH<Object> primitive order (insertion order when !use_bvh)
   std::vector<Light> lights;
   std::vector<LightTri> light_tris;  // indexed by (global triangle index - first light triangle)

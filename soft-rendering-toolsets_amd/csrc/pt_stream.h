@@ -139,7 +139,33 @@ struct CastParams {
   uint32_t obj_shift;
   unsigned long long* stats;   // STATS build only: CS_* sums over all waves
   const uint32_t* dev_cancel;  // srt_pt_cancel reached the device (pt_wave.h): nothing is cast
+  const float* tri_packed;     // triangle t's record without its padding: nine floats at tri_packed + 9 t (pt_scene.h)
 };
+
+// Triangle `tri` for the cast kernel, from the records without their padding (36 B: a leaf's <= 4 triangles are 144 contiguous bytes
+// instead of 192).  Round 4, on BASELINE configs[4]: interior records + triangles were 9.1 MB against the XCD's 4 MB of L2 and the
+// kernel's misses 42 % of the epoch's memory-side traffic; with 7.5 MB they fell from 125.6 to 86.5 GB per epoch (the kernel's time
+// did not move: it is bound by instruction issue, not by these misses).  Measured and dropped: the triangles as Tri_Mesh holds them -
+// three indices + shared vertices, 2.6 MB instead of 6.3, the edges subtracted on the spot, bit-identical - where the misses went UP,
+// 126 -> 198 GB (155 GB with the vertices renumbered by first use in the tree's order) and the kernel from 102 to 105.5 ms: four
+// small gathers per triangle are more lines asked for than one contiguous piece, and the second, dependent round trip is not hidden.
+#ifndef SRT_CAST_PACKED_TRIS
+#define SRT_CAST_PACKED_TRIS 1
+#endif
+struct __attribute__((packed, aligned(4))) TriPacked { float v[9]; };
+SRT_DEV Tri cast_load_tri(const DScene& S, const CastParams& P, uint32_t tri) {
+#if SRT_CAST_PACKED_TRIS
+  const TriPacked t = *reinterpret_cast<const TriPacked*>(P.tri_packed + ((tri << 3) + tri));
+  Tri g;
+  g.p0[0] = t.v[0]; g.p0[1] = t.v[1]; g.p0[2] = t.v[2]; g.p0[3] = 0.0f;
+  g.e1[0] = t.v[3]; g.e1[1] = t.v[4]; g.e1[2] = t.v[5]; g.e1[3] = 0.0f;
+  g.e2[0] = t.v[6]; g.e2[1] = t.v[7]; g.e2[2] = t.v[8]; g.e2[3] = 0.0f;
+  return g;
+#else
+  (void)P;
+  return *reinterpret_cast<const Tri*>(reinterpret_cast<const char*>(S.tris) + (((tri << 1) + tri) << 4));   // (48-byte records, tri * 48 < 2^32)
+#endif
+}
 
 // Dense list of the queue positions that carry a ray: the logic kernel left one mask word per path slot (bit q: queue slot
 // q); a block takes kCompactChunk consecutive path slots and appends its positions with ONE atomic.
@@ -377,7 +403,7 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
         if (hit && F.xf) {
           const Object& o = S.objects[F.obj_i];
           Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
-          const TriHit th = tri_hit(S.tris[tri], ray);
+          const TriHit th = tri_hit(cast_load_tri(S, P, tri), ray);
           const V3 pw = mat_point(o.trans, ray_at(ray, th.t));
           const V3 ow = mat_point(o.trans, ray.o);
           dist = norm(pw - ow);
@@ -527,8 +553,7 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
           const uint32_t tri = (uint32_t)__shfl((int)first, owner) + (ob >> 6);
           TriHit th; th.hit = false; th.dist = 0.0f;
           if ((uint32_t)lane < npairs) {
-            const char* tb = reinterpret_cast<const char*>(S.tris) + (((tri << 1) + tri) << 4);   // (48-byte records, tri * 48 < 2^32)
-            const Tri g = *reinterpret_cast<const Tri*>(tb);
+            const Tri g = cast_load_tri(S, P, tri);
             tri_hit_leafN<1>(&g, ray, &th);
           }
           const int hit_i = th.hit ? 1 : 0;
@@ -547,7 +572,7 @@ __global__ __launch_bounds__(256, WALK ? SRT_CAST_OCC_WALK : SRT_CAST_OCC) void 
           Ray ray; ray.o = F.co; ray.d = F.cd; ray.b0 = F.b0; ray.b1 = F.b1;
           F.ret = flat_no_hit();
           for (uint32_t i = 0; i < n; i++) {
-            const TriHit th = tri_hit(S.tris[first + i], ray);
+            const TriHit th = tri_hit(cast_load_tri(S, P, first + i), ray);
             fold(F.ret, th.hit, th.dist, 0, first + i);
           }
           F.mode = FM_UNWIND;
