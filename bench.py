@@ -530,7 +530,7 @@ def cfg5_bench(device, args, steps=4):
         "roofline": pt_roofline(cnt, rays / steps, kernel_ms, doc, why_not,
                                 "pt_wave_kernel<.., 4, .., 1> (resolve) + <.., 2> (probe) + pt_compact_kernel + pt_cast_kernel (every kernel of one epoch)" if form == 4 else str(form),
                                 scratch, {"stream_kernels_ms": split, "ray_state_terms": scratch_terms,
-                                          "working_set": "2.6 MB of interior records + 6.3 MB of triangles (+ 6.3 MB normals): L2 (4 MiB per XCD) / Infinity Cache resident"}),
+                                          "working_set": "2.8 MB of interior records + 4.7 MB of triangles as the cast kernel reads them (36-byte records; + 6.3 MB padded records and 6.3 MB normals for shading): L2 (4 MiB per XCD) / Infinity Cache resident"}),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = pt_cpu_baseline(scene, W, H, args.depth, args.seed, pt, budget_s=8.0)
