@@ -81,6 +81,44 @@ int dropin_raster_session(const char* path, int device, uint32_t w, uint32_t h, 
   return 0;
 }
 
+// Two tabs on ONE renderer, as the application's number keys switch them (drawsvg.cpp:400-414: the tab's viewport, then redraw):
+// `first` is drawn, then `second` on the same context; rgba_out[0] / rgba_out[1] (w*h*4 bytes each) receive the framebuffer after
+// each, refused_out the renderer's count of dropped frames after each.  What it is for: a tab whose content the device path refuses
+// (a line the reference's own loop never finishes) must leave a white frame and a renderer that draws the next tab correctly.
+int dropin_raster_two_tabs(const char* first, const char* second, int device, uint32_t w, uint32_t h, uint32_t sample_rate, uint8_t* rgba_out[2],
+                           uint32_t refused_out[2]) {
+  SoftwareRendererHIP* hip = new SoftwareRendererHIP(device);
+  SoftwareRenderer* software_renderer = hip;
+  Sampler2DImp* sampler = new Sampler2DImp();
+  software_renderer->set_tex_sampler(sampler);
+  std::vector<unsigned char> framebuffer(4 * (size_t)w * h);
+  software_renderer->set_render_target(&framebuffer[0], w, h);
+  Matrix3x3 norm_to_screen = Matrix3x3::identity();
+  float scale = std::min(w, h);
+  norm_to_screen(0, 0) = scale; norm_to_screen(0, 2) = (w - scale) / 2;
+  norm_to_screen(1, 1) = scale; norm_to_screen(1, 2) = (h - scale) / 2;
+  for (size_t rate = 2; rate <= sample_rate; rate++) software_renderer->set_sample_rate(rate);
+  const char* paths[2] = {first, second};
+  for (int t = 0; t < 2; t++) {
+    SVG* svg = new SVG();
+    if (SVGParser::load(paths[t], svg) < 0) return -1;
+    std::vector<Image*> images;
+    for (size_t i = 0; i < svg->elements.size(); ++i) collect_images(svg->elements[i], images);
+    for (Image* im : images) sampler->generate_mips(im->tex, 0);
+    ViewportImp* viewport = new ViewportImp();
+    const float sw = svg->width, sh = svg->height;
+    viewport->set_viewbox(sw / 2, sh / 2, 1.2 * std::max(sw, sh) / 2);
+    software_renderer->clear_target();
+    Matrix3x3 m_imp = norm_to_screen * viewport->get_svg_2_norm();
+    software_renderer->set_svg_2_screen(m_imp);
+    software_renderer->draw_svg(*svg);
+    std::memcpy(rgba_out[t], framebuffer.data(), framebuffer.size());
+    refused_out[t] = (uint32_t)hip->refused_frames();
+  }
+  delete hip;
+  return 0;
+}
+
 // Wall time of DrawSVG's redraw through the drop-in class, for bench.py.
 // The session is set up as in dropin_raster_session; then `frames` redraws are timed twice:
 //   ms_out[0]  the view moves every frame (the viewbox is nudged, as a pan does): the whole of DrawSVG::redraw - the application's

@@ -20,7 +20,24 @@ void die_on(int status, const char* what) {
 
 }  // namespace
 
-SoftwareRendererHIP::SoftwareRendererHIP(int device) : SoftwareRenderer(), ctx_(nullptr) {
+// A frame the device path REFUSES (SRT_ERR_UNSUPPORTED: content whose result the reference itself never produces - a line whose main
+// loop runs past 2^24, where `++x` on a float stops advancing and the reference hangs - or that exceeds a table limit) is dropped:
+// the reason goes to stderr (once per distinct reason), the target is left as clear_target() leaves it - white - and the
+// application keeps running; the next frame starts from srt_raster_clear like any other.  Nothing is drawn by another path.  Every other failure (no
+// device, a HIP error, a misuse of the ABI) still ends the process: the reference's surface has no error channel.
+bool SoftwareRendererHIP::frame_refused(int status, const char* what) {
+  if (status != SRT_ERR_UNSUPPORTED) { die_on(status, what); return false; }
+  const char* why = srt_last_error();
+  if (last_refusal_ != why) {
+    last_refusal_ = why;
+    std::fprintf(stderr, "[SoftwareRendererHIP] frame dropped, %s refused it: %s\n", what, why);
+  }
+  refused_frames_++;
+  if (render_target) std::memset(render_target, 255, 4 * target_w * target_h);
+  return true;
+}
+
+SoftwareRendererHIP::SoftwareRendererHIP(int device) : SoftwareRenderer(), ctx_(nullptr), refused_frames_(0) {
   render_target = nullptr;
   target_w = target_h = 0;
   die_on(srt_raster_create(device, &ctx_), "srt_raster_create");  // aborts without a HIP device: no CPU path
@@ -79,8 +96,8 @@ void SoftwareRendererHIP::draw_svg(SVG& svg) {
     }
     die_on(srt_raster_add_texture(ctx_, (uint32_t)n, w, h, lv, &id), "srt_raster_add_texture");
   }
-  die_on(srt_raster_submit(ctx_, stream.data(), stream.size()), "srt_raster_submit");
-  die_on(srt_raster_resolve(ctx_, render_target), "srt_raster_resolve");
+  if (frame_refused(srt_raster_submit(ctx_, stream.data(), stream.size()), "srt_raster_submit")) return;
+  if (frame_refused(srt_raster_resolve(ctx_, render_target), "srt_raster_resolve")) return;
 }
 
 }  // namespace CMU462

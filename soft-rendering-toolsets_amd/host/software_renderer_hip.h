@@ -15,6 +15,7 @@
 #ifndef SRT_SOFTWARE_RENDERER_HIP_H
 #define SRT_SOFTWARE_RENDERER_HIP_H
 
+#include <string>
 #include <vector>
 
 #include "software_renderer.h"  // the reference's header (CMU462::SoftwareRenderer)
@@ -35,8 +36,15 @@ class SoftwareRendererHIP : public SoftwareRenderer {
   // Mirrors SoftwareRendererImp::clear_target (software_renderer.h:93-98).
   void clear_target();
 
+  // Frames draw_svg dropped because the device path refused their content (see frame_refused in the .cpp); the reason of the last one.
+  size_t refused_frames() const { return refused_frames_; }
+  const std::string& last_refusal() const { return last_refusal_; }
+
  private:
+  bool frame_refused(int status, const char* what);
   srt_raster* ctx_;
+  size_t refused_frames_;
+  std::string last_refusal_;
   SvgStreamBuilder builder_;  // host half of draw_svg
 };
 
