@@ -328,6 +328,46 @@ def test_long_lines_and_growing_storage(srt):
     del rng
 
 
+def test_read_back_inside_the_tile_kernel_equals_the_copy_engine(srt):
+    """srt_raster_resolve into the framebuffer srt_raster_bind_output pinned: the tile kernel itself carries the finished groups of tiles
+    over (raster.hip: group_epilogue - write-through pixels, a flag per tile holding the launch's sequence number, the last wave of
+    a group copies).  One renderer with a bound target draws frame after frame - every frame's flags sit on the previous frame's,
+    every frame's pixels on the previous image - and each frame must equal what a fresh renderer WITHOUT a bound target reads back
+    with the copy engine: widths that are odd (4-byte path), not a multiple of a group of 16 tiles, a single group; sample rates
+    whose tiles are 32, 16, 10, 8 and 6 pixels wide; a target change in between (the flag array is re-made); triangles, lines,
+    points and images."""
+    from _cases import adversarial_stream, image_stream, line_stream, random_triangles
+
+    frame = 0
+    for w, h, sr in ((257, 130, 1), (512, 96, 2), (333, 77, 3), (1024, 64, 4), (96, 200, 5), (31, 9, 4), (640, 480, 1)):
+        target = np.zeros((h, w, 4), np.uint8)
+        ren = srt.SoftwareRenderer(0)
+        ren.set_render_target(target, w, h)
+        ren.set_sample_rate(sr)
+        img, level0 = image_stream(900 + w, w, h)
+        tex = H.Textures.from_level0(level0, H.oracle_generate_mips)
+        for t in range(len(tex)):
+            assert ren.add_texture(tex.texture(t)) == t
+        for k in range(6):
+            seed = 1000 * w + 10 * sr + k
+            if k % 3 == 0:
+                prims = random_triangles(seed, 40 + 25 * k, w, h, max(w, h) / 3)
+            elif k % 3 == 1:
+                prims = np.concatenate([line_stream(seed, w, h), adversarial_stream(seed, w, h)])
+            else:
+                prims = np.concatenate([random_triangles(seed, 30, w, h, max(w, h) / 2), img, line_stream(seed + 1, w, h)])
+            got = ren.draw_stream(prims)
+            assert got.ctypes.data == target.ctypes.data, "the frame is delivered into the bound framebuffer"
+            want, _, _ = render(srt, prims, w, h, sr, textures=tex)
+            assert np.array_equal(got, want), (w, h, sr, k)
+            frame += 1
+            if k == 3:                                            # the same stream again: the identical-stream shortcut, tiles + read-back only
+                target[...] = 7
+                assert np.array_equal(ren.draw_stream(prims), want)
+        ren.close()
+    assert frame == 42
+
+
 def test_unwalkable_lines_are_refused(srt):
     """The reference's main loop `for (float x = xpxl1 + 1; x <= xpxl2 - sample_rate; ++x)` never ends when x reaches 2^24 or is
     infinite; such a line is refused by the product (SRT_ERR_UNSUPPORTED at resolve) and by the oracle alike.  A line with NaN
