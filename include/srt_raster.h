@@ -125,11 +125,8 @@ int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out);
 
 /* Optional: tell the library that `host_rgba8` (bytes >= width*height*4) is the buffer srt_raster_resolve will be
  * handed from now on - DrawSVG lends one framebuffer per window size (set_render_target, drawsvg.cpp:107-114).  The
- * pages are pinned (hipHostRegister) and mapped into the device's address space: a srt_raster_resolve into the bound buffer is
- * delivered by the tile kernel itself, group of tiles by group of tiles, while the rest of the frame is still being rasterized
- * (round 4; for images below 1 GiB), instead of by a copy after the frame.  During such a resolve the buffer holds a mixture of
- * the previous and the new frame; it is complete on return, as always.  srt_raster_resolve works with any pointer; a bound one
- * is only faster.  The registration is released by the next
+ * pages are pinned (hipHostRegister), so the read-back of a frame is one DMA transfer instead of a staged pageable
+ * copy.  srt_raster_resolve works with any pointer; a bound one is only faster.  The registration is released by the next
  * bind (of another buffer or of NULL) or by srt_raster_destroy.  Preferably do that before the memory is freed; DrawSVG cannot
  * (DrawSVG::resize resizes its framebuffer vector BEFORE it calls set_render_target, drawsvg.cpp:111-114), and that order is
  * tolerated: releasing a registration removes the runtime's record of the pinned pages and never dereferences the range, and

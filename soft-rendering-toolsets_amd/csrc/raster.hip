@@ -56,8 +56,6 @@ struct RasterParams {
   uint32_t super_x, super_y;     // super grid (<= 8 x 8)
   uint32_t super_stride;         // entries reserved per super-bin (= nprims)
   uint32_t packed_ok;            // a coarse bin spans <= 256 samples per side: the bin lists' packed boxes (4 x 8 bits, bin-relative) are valid
-  uint32_t row_groups;           // read-back inside the tile kernel (raster_tiles: group_epilogue): groups of 16 tiles per row of tiles
-  uint32_t frame_seq;            // ... and what a flag of THIS launch holds
 };
 
 // Everything about one SRT_PRIM_IMAGE record that does not depend on the sample, prepared on the host at upload
@@ -99,8 +97,6 @@ static_assert(sizeof(LineAux) == 64, "LineAux is read with scalar loads, 64 byte
 // Device words a frame reports back (copied to the host with the image): what the line tables and the packed bin lists
 // needed (the host grows the buffers and repeats the frame when they did not fit), refusals.
 enum { FS_TABLE_NEED = 0, FS_LIST_NEED, FS_FLAGS, FS_COUNT };
-// behind the status words, in the same allocation (one kernel argument serves both): group_epilogue's flags and claim words
-constexpr uint32_t kBandCountAt = 64;
 constexpr uint32_t kFlagLineUnwalkable = 1u;   // a line whose main loop the reference's `++x` on a float could not walk
 
 // stats slots (unsigned long long each)
@@ -536,61 +532,6 @@ constexpr int kTileWavesPerBlock = SRT_RASTER_WPB;
 // a barrier among the lanes of ONE wave: LDS operations of a wave execute in program order, so what is needed is that the
 // compiler keeps them there
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-// The read-back inside the tile kernel (srt_raster_resolve into the framebuffer srt_raster_bind_output pinned).  The frame used to end
-// with a 4 MiB copy to the host AFTER the last tile (76 us of a 0.25 ms draw_svg at 1024^2; bands of tiles read back on a second stream
-// were measured in round 3: every cross-stream event costs ~35 us here).  Now 16 consecutive tiles of a row of tiles are a GROUP, and
-// the wave that finishes a group's last tile copies the group's pixels - tile_py row segments of 16 x tile_px pixels, 512 contiguous
-// bytes each at 1024^2 x 4 - from the device image into the pinned framebuffer: plain stores over PCIe (a kernel sustains 53 GB/s
-// there, tools/ubench/host_store.hip; the copy engine: 48) while the rest of the frame is still being rasterized.  No wave waits for
-// another: the last one to arrive does the work.
-//   Who is last is found without an atomic per tile: every tile stores a FLAG - the launch's sequence number, so nothing is ever reset -
-// waits until its stores are acknowledged, and reads the 16 flags of its group (one 64-byte line): whoever sees them all set was
-// (among) the last, and one exchange on the group's claim word elects a single wave.
-//   The tiles of a group run on different XCDs, each with its own L2: pixels and flags are stored write-through (`sc1`), flags and the
-// group's pixels are read back past the L2 (`sc1` loads) after the wave's own stores are acknowledged.
-//   Measured on BASELINE configs[1] (tile kernel 90 us on its own, copy engine 76 us behind it): the kernel takes 147 us with the
-// transfer inside - draw_svg 0.259 -> 0.234 ms.  Not the 95 us a perfect overlap would give: with the stores towards the host in
-// flight, the tiles' write-through stores are acknowledged late, and every tile wave waits for its acknowledgements.  Other forms
-// built and measured: counters instead of flags (atomics of the whole device on ONE word are served one after the other, ~10 per
-// microsecond: 0.58 ms per frame with a counter per 512 tiles, 0.23 with two levels of counters - no better than flags); whole rows
-// of tiles as the unit (150 us); a release at agent scope per tile instead of write-through stores (a write-back of the XCD's whole
-// L2, `buffer_wbl2`, 65 536 times a frame: 1.0 ms per frame); an acquire at agent scope before the copy instead of `sc1` loads (no
-// difference); dedicated copier workgroups in front of the tiles' that poll the flags and copy, 32 .. 256 of them, so that tile
-// waves never read a flag (bit-exact, 167-208 us).
-__device__ __forceinline__ void store_pixel(uint32_t* p, uint32_t v, bool through) {
-  if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-__device__ __forceinline__ void group_epilogue(const RasterParams& P, int tx, int ty, const uint32_t* __restrict__ rgba_out, uint32_t* __restrict__ host_out,
-                                               uint32_t* __restrict__ words, int lane) {
-  // (32-bit arithmetic throughout - srt_raster_resolve takes this path only for images below 2^30 bytes: the kernel is short of scalar registers)
-  const uint32_t seq = P.frame_seq;
-  const uint32_t gx = (uint32_t)tx >> 4, group = (uint32_t)ty * P.row_groups + gx;
-  const uint32_t cnt = min(16u, P.tiles_x - (gx << 4));
-  uint32_t* flags = words + (group << 4);                 // words: [tile flags: 16 per group][claims: one per group]
-  if (lane == 0) __hip_atomic_store(flags + ((uint32_t)tx & 15u), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);                          // vmcnt(0) expcnt(0) lgkmcnt(0): everything this wave stored has been acknowledged
-  uint32_t f = seq;
-  if ((uint32_t)lane < cnt) f = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (__ballot(f != seq) != 0ull) return;
-  uint32_t old = seq;
-  if (lane == 0) old = __hip_atomic_exchange(words + ((P.row_groups * P.tiles_y) << 4) + group, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((uint32_t)__builtin_amdgcn_readfirstlane((int)old) == seq) return;
-  const uint32_t x0 = (gx << 4) * P.tile_px, seg = min(P.w - x0, cnt * P.tile_px);          // pixels
-  const uint32_t y0 = (uint32_t)ty * P.tile_py, y1 = min(P.h, y0 + P.tile_py);
-  if (((P.w | seg) & 1u) == 0u) {                         // 8 bytes per lane
-    for (uint32_t y = y0; y < y1; y++) {
-      const unsigned long long* __restrict__ src = reinterpret_cast<const unsigned long long*>(rgba_out + y * P.w + x0);
-      unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(host_out + y * P.w + x0);
-      for (uint32_t i = (uint32_t)lane; i < (seg >> 1); i += WAVE) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else {
-    for (uint32_t y = y0; y < y1; y++)
-      for (uint32_t i = (uint32_t)lane; i < seg; i += WAVE) host_out[y * P.w + x0 + i] = __hip_atomic_load(rgba_out + y * P.w + x0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 template <bool STATS, int TSY, bool IMG>
 // (five waves per SIMD where the tile's LDS leaves room for them - 96 VGPRs, 7 spilled: 8-sample-high tiles at 20 waves per CU
 //  measure 6 % faster on cfg2 than 16-high ones at 16; six and eight waves per SIMD lose to their spills)
@@ -615,8 +556,7 @@ __global__ __launch_bounds__(WAVE * (TSY == 32 ? 1 : SRT_RASTER_WPB), TSY == 32 
                                                      uint32_t* __restrict__ rgba_out,
                                                      float4* __restrict__ samples_out,
                                                      unsigned long long* __restrict__ stats,
-                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ host_status,
-                                                     uint32_t* __restrict__ host_out) {
+                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ host_status) {
   constexpr int WPB = TSY == 32 ? 1 : kTileWavesPerBlock;
   // per wave: the tile's slice of super_sample_buffer (4 / 8 / 16 KiB), y / sample_rate for each tile row and x / sample_rate for each
   // tile column (fp64 divisions done once) - ONE block of LDS per wave, so that one (scalar) base serves all three
@@ -889,11 +829,10 @@ __global__ __launch_bounds__(WAVE * (TSY == 32 ? 1 : SRT_RASTER_WPB), TSY == 32 
   const bool pow2_sr = (P.sr & (P.sr - 1u)) == 0u;
   const float inv_denom = 1.0f / denom;
   if (!touched) {                                        // an untouched tile: every pixel (255, 255, 255, 255), every sample 255.0f
-    for (int k = lane; k < pw * ph; k += WAVE) store_pixel(rgba_out + ((size_t)(py0 + k / pw) * P.w + (px0 + k % pw)), 0xFFFFFFFFu, host_out != nullptr);
+    for (int k = lane; k < pw * ph; k += WAVE) rgba_out[(size_t)(py0 + k / pw) * P.w + (px0 + k % pw)] = 0xFFFFFFFFu;
     if (samples_out)
       for (int k = lane; k < tsw * tsh; k += WAVE) samples_out[(size_t)(sy0 + k / tsw) * P.ssw + (sx0 + k % tsw)] = white;
     if (STATS && lane == 0) atomicAdd(&stats[ST_BIN_ENTRIES], n_bins);
-    if (host_out) group_epilogue(P, tx, ty, rgba_out, host_out, status + kBandCountAt, lane);
     return;
   }
   for (int k = lane; k < pw * ph; k += WAVE) {
@@ -909,7 +848,7 @@ __global__ __launch_bounds__(WAVE * (TSY == 32 ? 1 : SRT_RASTER_WPB), TSY == 32 
     else { r /= denom; g /= denom; bl /= denom; a /= denom; }
     const uint32_t R = (uint32_t)(uint8_t)(r), G = (uint32_t)(uint8_t)(g), B = (uint32_t)(uint8_t)(bl),
                    A = (uint32_t)(uint8_t)(a);
-    store_pixel(rgba_out + ((size_t)(py0 + pyl) * P.w + (px0 + pxl)), R | (G << 8) | (B << 16) | (A << 24), host_out != nullptr);
+    rgba_out[(size_t)(py0 + pyl) * P.w + (px0 + pxl)] = R | (G << 8) | (B << 16) | (A << 24);
   }
 
   if (samples_out) {
@@ -926,7 +865,6 @@ __global__ __launch_bounds__(WAVE * (TSY == 32 ? 1 : SRT_RASTER_WPB), TSY == 32 
       atomicAdd(&stats[ST_BIN_ENTRIES], n_bins);
     }
   }
-  if (host_out) group_epilogue(P, tx, ty, rgba_out, host_out, status + kBandCountAt, lane);
 }
 
 }  // namespace
@@ -962,9 +900,7 @@ struct srt_raster {
   bool has_images = false;                             // the stream on the device holds SRT_PRIM_IMAGE records (the tile kernel's IMG build)
   LineAux* d_laux = nullptr; size_t laux_cap = 0;
   float* d_ltable = nullptr; size_t ltable_cap = 0;
-  uint32_t* d_status = nullptr;                        // FS_* words of the frame in flight (+ group_epilogue's flags behind them)
-  size_t status_words = kBandCountAt;
-  uint32_t frame_seq = 0;
+  uint32_t* d_status = nullptr;                        // FS_* words of the frame in flight
   uint32_t* h_status = nullptr;                        // ... written here (pinned, device-visible) by the tile kernel's first block
   uint32_t* d_host_status = nullptr;                   // its device address
   uint32_t* d_rgba = nullptr;
@@ -972,8 +908,6 @@ struct srt_raster {
   unsigned long long* d_stats = nullptr;
   bool resolved = false;
   uint8_t* bound_out = nullptr;                        // srt_raster_bind_output: the caller's framebuffer, pinned
-  uint8_t* bound_dev = nullptr;                        // ... as the device sees it (the tile kernel writes finished groups of tiles into it)
-  size_t bound_bytes = 0;
   // textures (srt_raster_add_texture): host copies, then one device blob with 4-byte aligned levels
   struct Tex { uint32_t nlevels; uint32_t w[SRT_MAX_MIP_LEVELS], h[SRT_MAX_MIP_LEVELS]; size_t off[SRT_MAX_MIP_LEVELS]; };
   std::vector<Tex> textures, prev_textures;
@@ -1210,7 +1144,7 @@ void set_grid(RasterParams& P, uint32_t c) {
 // Nothing here waits for the device.  The line tables and the packed bin lists live in storage that is kept across frames and
 // sized by what earlier frames needed (a first guess for the very first one): a frame whose needs exceed it leaves the
 // affected lists / tables empty and says so in its status - check_frame() then grows the storage and the caller repeats the frame.
-int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats, uint8_t* host_out = nullptr) {
+int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats) {
   RasterParams& P = r->P;
   if (stats) SRT_HIP(hipMemsetAsync(r->d_stats, 0, ST_COUNT * sizeof(unsigned long long), s));
   if (!r->bins_valid || stats) {
@@ -1245,30 +1179,10 @@ int launch_frame(srt_raster* r, hipStream_t s, bool dump_samples, bool stats, ui
   }
   const uint32_t ntiles = P.tiles_x * P.tiles_y;
   float4* so = dump_samples ? r->d_samples : nullptr;
-  if (host_out) {                                  // the read-back inside the tile kernel: group_epilogue's flags and claims
-    P.row_groups = (P.tiles_x + 15u) >> 4;
-    const size_t ngroups = (size_t)P.row_groups * P.tiles_y;
-    const size_t words = (size_t)kBandCountAt + ngroups * 17;
-    if (words > r->status_words) {                 // (the flags grow with the target; zeroed once - a flag is the launch's sequence number)
-      uint32_t* grown = nullptr;
-      SRT_HIP(hipMalloc(&grown, words * sizeof(uint32_t)));
-      SRT_HIP(hipMemsetAsync(grown, 0, words * sizeof(uint32_t), s));
-      SRT_HIP(hipMemcpyAsync(grown, r->d_status, FS_COUNT * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-      SRT_HIP(hipStreamSynchronize(s));
-      (void)hipFree(r->d_status);
-      r->d_status = grown; r->status_words = words;
-    }
-    if (++r->frame_seq == 0u) {                    // (2^32 launches later: a stale flag could pass for a fresh one)
-      SRT_HIP(hipMemsetAsync(r->d_status + kBandCountAt, 0, (r->status_words - kBandCountAt) * sizeof(uint32_t), s));
-      r->frame_seq = 1u;
-    }
-    P.frame_seq = r->frame_seq;
-  }
 #define SRT_TILES2(STATS_, TSY_, IMG_, ST_)                                                                                 \
   raster_tiles<STATS_, TSY_, IMG_><<<dim3((ntiles + (TSY_ == 32 ? 1 : kTileWavesPerBlock) - 1) / (TSY_ == 32 ? 1 : kTileWavesPerBlock)), dim3(WAVE * (TSY_ == 32 ? 1 : kTileWavesPerBlock)), 0, s>>>(P, r->d_prims, r->d_bbox, reinterpret_cast<const uint32_t*>(r->d_lists), r->d_counts, \
                                                                  r->d_counts + (size_t)P.coarse_x * P.coarse_y, r->d_aux,       \
-                                                                 r->d_tabs, r->d_texels, r->d_laux, r->d_ltable, r->d_rgba, so, ST_, r->d_status, r->d_host_status,   \
-                                                                 reinterpret_cast<uint32_t*>(host_out))
+                                                                 r->d_tabs, r->d_texels, r->d_laux, r->d_ltable, r->d_rgba, so, ST_, r->d_status, r->d_host_status)
 #define SRT_TILES(STATS_, TSY_, ST_) do { if (r->has_images) SRT_TILES2(STATS_, TSY_, true, ST_); else SRT_TILES2(STATS_, TSY_, false, ST_); } while (0)
   const int tsy = P.tile_sy > 16 ? 32 : (P.tile_sy > 8 ? 16 : 8);
   if (stats) { if (tsy == 32) SRT_TILES(true, 32, r->d_stats); else if (tsy == 16) SRT_TILES(true, 16, r->d_stats); else SRT_TILES(true, 8, r->d_stats); }
@@ -1354,8 +1268,8 @@ int srt_raster_create(int device, srt_raster** out) {
     return srt::fail(SRT_ERR_HIP, "hipStreamCreate failed");
   }
   if (hipMalloc(&r->d_stats, ST_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc(&r->d_status, kBandCountAt * sizeof(uint32_t)) != hipSuccess ||
-      hipMemset(r->d_status, 0, kBandCountAt * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(&r->d_status, FS_COUNT * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(r->d_status, 0, FS_COUNT * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc((void**)&r->h_status, FS_COUNT * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&r->d_host_status, r->h_status, 0) != hipSuccess) {
     (void)hipFree(r->d_stats); (void)hipFree(r->d_status);
@@ -1562,7 +1476,7 @@ int srt_raster_bind_output(srt_raster* r, uint8_t* host_rgba8, size_t bytes) {
   SRT_HIP(hipStreamSynchronize(r->stream));
   if (r->bound_out) {
     if (hipHostUnregister(r->bound_out) != hipSuccess) (void)hipGetLastError();   // (the memory may be gone already: nothing to undo then)
-    r->bound_out = nullptr; r->bound_dev = nullptr; r->bound_bytes = 0;
+    r->bound_out = nullptr;
   }
   if (!host_rgba8 || !bytes) return SRT_OK;
   if (hipHostRegister(host_rgba8, bytes, hipHostRegisterDefault) != hipSuccess) {
@@ -1570,10 +1484,6 @@ int srt_raster_bind_output(srt_raster* r, uint8_t* host_rgba8, size_t bytes) {
     return SRT_OK;
   }
   r->bound_out = host_rgba8;
-  r->bound_bytes = bytes;
-  void* dev = nullptr;
-  if (hipHostGetDevicePointer(&dev, host_rgba8, 0) == hipSuccess) r->bound_dev = (uint8_t*)dev;
-  else (void)hipGetLastError();                    // (the copy engine then brings the frame over, as for an unbound buffer)
   return SRT_OK;
 }
 
@@ -1600,17 +1510,11 @@ int srt_raster_resolve(srt_raster* r, uint8_t* rgba8_out) {
   SRT_HIP(hipSetDevice(r->device));
   if (r->dirty) { int st = upload_stream(r); if (st != SRT_OK) return st; }
   // frame and read-back are enqueued together; one wait.  (A frame whose storage has to grow is repeated: run_frame.)
-  // Into the bound framebuffer the tile kernel itself delivers the image, group of tiles by group of tiles, while it runs (group_epilogue); anywhere
-  // else the copy engine does, after the frame.
-  static const bool no_direct = getenv("SRT_RASTER_NO_DIRECT") != nullptr;     // (A/B switch for measurements)
-  const size_t image_bytes = (size_t)r->P.w * r->P.h * 4;
-  uint8_t* direct = (!no_direct && rgba8_out == r->bound_out && r->bound_dev && image_bytes <= r->bound_bytes && image_bytes < (1ull << 30)) ? r->bound_dev : nullptr;
   for (int attempt = 0; attempt < kMaxFrameAttempts; attempt++) {
-    int st = launch_frame(r, r->stream, false, false, direct);
+    int st = launch_frame(r, r->stream, false, false);
     if (st != SRT_OK) return st;
-    if (!direct) SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, image_bytes, hipMemcpyDeviceToHost, r->stream));
+    SRT_HIP(hipMemcpyAsync(rgba8_out, r->d_rgba, (size_t)r->P.w * r->P.h * 4, hipMemcpyDeviceToHost, r->stream));
     SRT_HIP(hipStreamSynchronize(r->stream));
-
     st = check_frame(r);
     if (st < 0) return st;
     if (st == 0) return SRT_OK;

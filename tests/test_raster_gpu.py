@@ -328,18 +328,16 @@ def test_long_lines_and_growing_storage(srt):
     del rng
 
 
-def test_read_back_inside_the_tile_kernel_equals_the_copy_engine(srt):
-    """srt_raster_resolve into the framebuffer srt_raster_bind_output pinned: the tile kernel itself carries the finished groups of tiles
-    over (raster.hip: group_epilogue - write-through pixels, a flag per tile holding the launch's sequence number, the last wave of
-    a group copies).  One renderer with a bound target draws frame after frame - every frame's flags sit on the previous frame's,
-    every frame's pixels on the previous image - and each frame must equal what a fresh renderer WITHOUT a bound target reads back
-    with the copy engine: widths that are odd (4-byte path), not a multiple of a group of 16 tiles, a single group; sample rates
-    whose tiles are 32, 16, 10, 8 and 6 pixels wide; a target change in between (the flag array is re-made); triangles, lines,
-    points and images."""
+def test_frames_into_a_lent_framebuffer_equal_frames_into_a_fresh_one(srt):
+    """srt_raster_resolve into the framebuffer srt_raster_bind_output pinned (what DrawSVG lends its renderer) against a fresh renderer
+    that allocates its own pageable output: one renderer with a bound target draws frame after frame - every frame's pixels land on the
+    previous image - widths that are odd or no multiple of anything, sample rates whose tiles are 32, 16, 10, 8 and 6 pixels wide, a
+    target change in between, triangles, lines, points and images, up to 1920 x 1080.  (Round 4 built a read-back INSIDE the tile kernel
+    on this path and removed it again - DESIGN.md section 1; this test is what caught its first hole, at 1920 x 1080.)"""
     from _cases import adversarial_stream, image_stream, line_stream, random_triangles
 
     frame = 0
-    for w, h, sr in ((257, 130, 1), (512, 96, 2), (333, 77, 3), (1024, 64, 4), (96, 200, 5), (31, 9, 4), (640, 480, 1)):
+    for w, h, sr in ((257, 130, 1), (512, 96, 2), (333, 77, 3), (1024, 64, 4), (96, 200, 5), (31, 9, 4), (640, 480, 1), (1024, 1024, 4), (1920, 1080, 2)):
         target = np.zeros((h, w, 4), np.uint8)
         ren = srt.SoftwareRenderer(0)
         ren.set_render_target(target, w, h)
@@ -357,7 +355,7 @@ def test_read_back_inside_the_tile_kernel_equals_the_copy_engine(srt):
             else:
                 prims = np.concatenate([random_triangles(seed, 30, w, h, max(w, h) / 2), img, line_stream(seed + 1, w, h)])
             got = ren.draw_stream(prims)
-            assert got.ctypes.data == target.ctypes.data, "the frame is delivered into the bound framebuffer"
+            assert got.ctypes.data == target.ctypes.data, "the frame is delivered into the lent framebuffer"
             want, _, _ = render(srt, prims, w, h, sr, textures=tex)
             assert np.array_equal(got, want), (w, h, sr, k)
             frame += 1
@@ -365,7 +363,7 @@ def test_read_back_inside_the_tile_kernel_equals_the_copy_engine(srt):
                 target[...] = 7
                 assert np.array_equal(ren.draw_stream(prims), want)
         ren.close()
-    assert frame == 42
+    assert frame == 54
 
 
 def test_unwalkable_lines_are_refused(srt):

@@ -55,7 +55,9 @@ for seed in range(first, first + count):
     prims = np.concatenate(parts)
     prims = prims[rng.permutation(len(prims))] if len(prims) else prims
     ren = srt_amd.SoftwareRenderer(0)
-    ren.set_render_target(None, w, h)
+    # odd seeds lend the renderer a framebuffer, as DrawSVG does (pinned: srt_raster_bind_output)
+    lent = np.full((h, w, 4), 9, np.uint8) if seed & 1 else None
+    ren.set_render_target(lent, w, h)
     ren.set_sample_rate(sr)
     for t in range(len(textures) if textures is not None else 0):
         ren.add_texture(textures.texture(t))
